@@ -1,0 +1,162 @@
+/*
+ * lucid_raster.h -- C-ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary under LucidDreamer's `depth_diff_gaussian_rasterization_min`
+ * extension.  Each entry point replaces one static method of the reference's
+ * CudaRasterizer::Rasterizer (RAST/ = /root/reference/submodules/depth-diff-gaussian-rasterization-min/):
+ *
+ *   lr_forward       <->  Rasterizer::forward      RAST/cuda_rasterizer/rasterizer.h:31-55,
+ *                                                  RAST/cuda_rasterizer/rasterizer_impl.cu:198-339
+ *   lr_backward      <->  Rasterizer::backward     RAST/cuda_rasterizer/rasterizer.h:57-86,
+ *                                                  RAST/cuda_rasterizer/rasterizer_impl.cu:343-444
+ *   lr_mark_visible  <->  Rasterizer::markVisible  RAST/cuda_rasterizer/rasterizer.h:24-29,
+ *                                                  RAST/cuda_rasterizer/rasterizer_impl.cu:141-153
+ *   lr_dist2         <->  SimpleKNN::knn           /root/reference/submodules/simple-knn/simple_knn.h,
+ *                                                  simple_knn.cu:186-221 (distCUDA2, spatial.cu:15-26)
+ *
+ * Plain pointers and sizes only (no torch types).  All pointers are DEVICE pointers (HBM) unless
+ * stated otherwise; all arrays are dense row-major float32/int32 exactly as the reference lays
+ * them out.  Differences from the reference signature, all additive:
+ *   - the three std::function<char*(size_t)> allocators become C callbacks + a user cookie;
+ *   - every call takes the HIP stream to enqueue on (the reference uses the legacy default stream);
+ *   - lr_forward takes `binning_capacity` (see below) to run WITHOUT the per-view host sync;
+ *   - errors are returned as negative codes (lr_last_error() gives the text) instead of C++
+ *     exceptions / device traps;
+ *   - gradient outputs of lr_backward need NOT be zero-filled by the caller.
+ *
+ * Optional inputs (shs / colors_precomp, scales+rotations / cov3D_precomp) are NULL when absent
+ * (the reference tests the pointer for nullptr: forward.cu:205,241; backward.cu:390,394).
+ */
+#ifndef LUCID_RASTER_H_INCLUDED
+#define LUCID_RASTER_H_INCLUDED
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Allocator callback: must return a device pointer to at least `bytes` bytes, 256-byte aligned,
+ * that stays valid until the matching lr_backward has completed
+ * (replaces std::function<char*(size_t)>, RAST/rasterize_points.cu:27-33). */
+typedef char* (*lr_alloc_fn)(size_t bytes, void* user);
+
+/* Error codes (negative return values). */
+#define LR_ERR_INVALID_ARG   (-10)  /* bad shapes / NULL required pointer / non-RGB (rasterizer_impl.cu:243-246) */
+#define LR_ERR_HIP           (-11)  /* a HIP runtime call failed (debug => after a stream sync, auxiliary.h:166-173) */
+#define LR_ERR_PREFILTERED   (-12)  /* "Point is filtered although prefiltered is set" (auxiliary.h:156-160) */
+#define LR_ERR_OVERFLOW      (-13)  /* async mode: num_rendered exceeded binning_capacity */
+#define LR_ERR_ALLOC         (-14)  /* allocator callback returned NULL */
+#define LR_NUM_RENDERED_ON_DEVICE (-1) /* lr_forward return value in async mode */
+
+const char* lr_last_error(void);
+const char* lr_version(void);
+
+/* Scratch sizes (bytes).  geom depends on P only, img on W,H only, binning on the number of
+ * tile instances R (num_rendered) -- cf. required<GeometryState/ImageState/BinningState>,
+ * RAST/cuda_rasterizer/rasterizer_impl.cu:226, 239, 284. */
+size_t lr_geom_bytes(int P);
+size_t lr_img_bytes(int width, int height);
+size_t lr_binning_bytes(long long R);
+
+/*
+ * Forward.  Returns num_rendered (>= 0) in exact mode, LR_NUM_RENDERED_ON_DEVICE in async mode,
+ * or a negative LR_ERR_*.
+ *
+ * binning_capacity == 0  (exact mode, reference behaviour): after the tile-count scan the host
+ *     reads num_rendered back (one 4-byte D2H + stream sync, as rasterizer_impl.cu:281-282) and
+ *     sizes the binning buffer exactly.
+ * binning_capacity  > 0  (async mode): no host synchronisation at all.  The binning buffer is
+ *     sized for `binning_capacity` tile instances; num_rendered stays in the geom buffer header.
+ *     If the view needs more, nothing is written out of bounds, the overflow flag in the header
+ *     is set and lr_backward / lr_check return LR_ERR_OVERFLOW.
+ *
+ * out_color [3,H,W], out_depth [1,H,W], radii [P] are fully written (no pre-fill needed).
+ */
+int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
+               lr_alloc_fn binning_alloc, void* binning_user,
+               lr_alloc_fn img_alloc, void* img_user,
+               int P, int D, int M,
+               const float* background,
+               int width, int height,
+               const float* means3D,
+               const float* shs,
+               const float* colors_precomp,
+               const float* opacities,
+               const float* scales,
+               float scale_modifier,
+               const float* rotations,
+               const float* cov3D_precomp,
+               const float* viewmatrix,
+               const float* projmatrix,
+               const float* cam_pos,
+               float tan_fovx, float tan_fovy,
+               int prefiltered,
+               float* out_color,
+               float* out_depth,
+               int* radii,
+               int debug,
+               long long binning_capacity,
+               void* stream);
+
+/*
+ * Backward.  R is the value lr_forward returned and binning_capacity the value it was given
+ * (exact mode: R >= 0, capacity 0; async mode: R = LR_NUM_RENDERED_ON_DEVICE, capacity > 0; no host
+ * synchronisation happens in either mode -- use lr_check to learn about an overflow).  dL_depths is accepted and ignored, exactly as the reference does
+ * (RAST/cuda_rasterizer/backward.cu:457-464, 539-554 are commented out).
+ * Outputs (all fully written, rows of culled Gaussians are zero):
+ *   dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (slots x,y,w; may be NULL), dL_dopacity [P],
+ *   dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL iff shs NULL),
+ *   dL_dscale [P,3], dL_drot [P,4] (written as zeros when cov3D_precomp is used).
+ * Returns 0 or a negative LR_ERR_*.
+ */
+int lr_backward(int P, int D, int M, int R,
+                const float* background,
+                int width, int height,
+                const float* means3D,
+                const float* shs,
+                const float* colors_precomp,
+                const float* scales,
+                float scale_modifier,
+                const float* rotations,
+                const float* cov3D_precomp,
+                const float* viewmatrix,
+                const float* projmatrix,
+                const float* campos,
+                float tan_fovx, float tan_fovy,
+                const int* radii,
+                char* geom_buffer,
+                char* binning_buffer,
+                char* image_buffer,
+                const float* dL_dpix,
+                const float* dL_depths,
+                float* dL_dmean2D,
+                float* dL_dconic,
+                float* dL_dopacity,
+                float* dL_dcolor,
+                float* dL_dmean3D,
+                float* dL_dcov3D,
+                float* dL_dsh,
+                float* dL_dscale,
+                float* dL_drot,
+                int debug,
+                long long binning_capacity,
+                void* stream);
+
+/* present[P] (1 byte each) = view-space z > 0.2.  Returns 0 or a negative LR_ERR_*. */
+int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    unsigned char* present, void* stream);
+
+/* Synchronises `stream` and reports the header state of a geom buffer written by lr_forward:
+ * num_rendered via *num_rendered (may be NULL); returns 0, LR_ERR_OVERFLOW or LR_ERR_PREFILTERED. */
+int lr_check(const char* geom_buffer, long long* num_rendered, void* stream);
+
+/* Mean squared distance to the 3 nearest other points (simple-knn distCUDA2).
+ * points [P,3] -> out [P].  workspace: lr_dist2_workspace_bytes(P) device bytes. */
+size_t lr_dist2_workspace_bytes(int P);
+int lr_dist2(int P, const float* points, float* out, char* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LUCID_RASTER_H_INCLUDED */

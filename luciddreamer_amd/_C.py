@@ -1,0 +1,188 @@
+"""Drop-in replacement of the reference's pybind11 module `depth_diff_gaussian_rasterization_min._C`.
+
+Same three functions, same positional arguments, same return tuples:
+    rasterize_gaussians           RAST/rasterize_points.h:18-38,  RAST/rasterize_points.cu:35-117
+    rasterize_gaussians_backward  RAST/rasterize_points.h:40-63,  RAST/rasterize_points.cu:119-200
+    mark_visible                  RAST/rasterize_points.h:65-68,  RAST/rasterize_points.cu:202-221
+Tensors are torch tensors on a HIP device; the work is done by liblucid_raster.so through its
+C-ABI (include/lucid_raster.h) on the CURRENT torch stream.  torch is used here only for device
+memory and streams.
+
+Beyond the reference's contract (all optional, keyword-only):
+    binning_capacity : > 0 runs lr_forward in async mode (no host sync; see lucid_raster.h)
+"""
+import threading
+
+import torch
+
+from . import _lib
+
+NUM_CHANNELS = 3
+_tls = threading.local()
+
+
+def _alloc_cb(nbytes, user):
+    """lr_alloc_fn: allocate a torch uint8 tensor on the call's device and remember it in slot `user`."""
+    call = _tls.call
+    t = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=call["device"])
+    call["bufs"][int(user or 0)] = t
+    return t.data_ptr()
+
+
+_ALLOC = _lib.ALLOC_FN(_alloc_cb)
+
+
+def _require_device(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"luciddreamer_amd: {name} must be on a HIP device (got {t.device}); this rasterizer has no CPU path "
+            "(neither has the reference: RAST/rasterize_points.cu:72)")
+
+
+def _f32(t, device, name):
+    """float32, contiguous, on `device`; empty tensors (the reference's `torch.Tensor([])` placeholders,
+    RAST/.../__init__.py:198-208) become None."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if t.device != device:
+        t = t.to(device)
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug, *, binning_capacity=0):
+    if means3D.ndimension() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")          # rasterize_points.cu:57-59
+    _require_device(means3D, "means3D")
+    dev = means3D.device
+    L = _lib.lib()
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    if P == 0:
+        # rasterize_points.cu:68-82: zero images, empty scratch, nothing launched
+        empty = torch.empty((0,), dtype=torch.uint8, device=dev)
+        return 0, out_color.zero_(), out_depth.zero_(), radii, empty, empty.clone(), empty.clone()
+
+    means3D_c = _f32(means3D, dev, "means3D")
+    bg = _f32(background, dev, "background")
+    colors_c = _f32(colors, dev, "colors_precomp")
+    opacity_c = _f32(opacity, dev, "opacities")
+    scales_c = _f32(scales, dev, "scales")
+    rot_c = _f32(rotations, dev, "rotations")
+    cov_c = _f32(cov3D_precomp, dev, "cov3D_precomp")
+    view = _f32(viewmatrix, dev, "viewmatrix")
+    proj = _f32(projmatrix, dev, "projmatrix")
+    cam = _f32(campos, dev, "campos")
+    sh_c = _f32(sh, dev, "sh")
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0 and sh.size(0) != 0) else 0  # rasterize_points.cu:84-88
+
+    call = {"device": dev, "bufs": [None, None, None]}
+    _tls.call = call
+    try:
+        with torch.cuda.device(dev):
+            rc = L.lr_forward(_ALLOC, 0, _ALLOC, 1, _ALLOC, 2, P, int(degree), M, _ptr(bg), W, H,
+                              _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c),
+                              float(scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view), _ptr(proj), _ptr(cam),
+                              float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                              out_color.data_ptr(), out_depth.data_ptr(), radii.data_ptr(), int(bool(debug)),
+                              int(binning_capacity), _stream(dev))
+    finally:
+        _tls.call = None
+    if rc < 0 and rc != _lib.LR_NUM_RENDERED_ON_DEVICE:
+        _lib.raise_for(rc, "rasterize_gaussians")
+    geom, binning, img = call["bufs"]
+    if binning is None:
+        binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+    return rc, out_color, out_depth, radii, geom, binning, img
+
+
+def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
+                                 dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
+                                 debug, *, binning_capacity=0):
+    _require_device(means3D, "means3D")
+    dev = means3D.device
+    L = _lib.lib()
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0 and sh.size(0) != 0) else 0
+
+    # All nine are fully written by the library (culled rows = 0): no zero-fill (cf. rasterize_points.cu:154-162).
+    opt = dict(dtype=torch.float32, device=dev)
+    dL_dmeans3D = torch.empty((P, 3), **opt)
+    dL_dmeans2D = torch.empty((P, 3), **opt)
+    dL_dcolors = torch.empty((P, NUM_CHANNELS), **opt)
+    dL_dopacity = torch.empty((P, 1), **opt)
+    dL_dcov3D = torch.empty((P, 6), **opt)
+    dL_dsh = torch.empty((P, M, 3), **opt)
+    dL_dscales = torch.empty((P, 3), **opt)
+    dL_drotations = torch.empty((P, 4), **opt)
+    if P != 0:
+        means3D_c = _f32(means3D, dev, "means3D")
+        bg = _f32(background, dev, "background")
+        colors_c = _f32(colors, dev, "colors_precomp")
+        scales_c = _f32(scales, dev, "scales")
+        rot_c = _f32(rotations, dev, "rotations")
+        cov_c = _f32(cov3D_precomp, dev, "cov3D_precomp")
+        view = _f32(viewmatrix, dev, "viewmatrix")
+        proj = _f32(projmatrix, dev, "projmatrix")
+        cam = _f32(campos, dev, "campos")
+        sh_c = _f32(sh, dev, "sh")
+        g_color = _f32(dL_dout_color, dev, "dL_dout_color")
+        g_depth = _f32(dL_dout_depth, dev, "dL_dout_depth") if dL_dout_depth is not None else None
+        radii_c = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = L.lr_backward(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(means3D_c), _ptr(sh_c),
+                               _ptr(colors_c), _ptr(scales_c), float(scale_modifier), _ptr(rot_c), _ptr(cov_c),
+                               _ptr(view), _ptr(proj), _ptr(cam), float(tan_fovx), float(tan_fovy),
+                               radii_c.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
+                               imageBuffer.data_ptr(), _ptr(g_color), _ptr(g_depth),
+                               dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
+                               dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh) if M else None,
+                               dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
+                               int(binning_capacity), _stream(dev))
+        if rc < 0:
+            _lib.raise_for(rc, "rasterize_gaussians_backward")
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    _require_device(means3D, "means3D")
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.empty((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m = _f32(means3D, dev, "means3D")
+        v = _f32(viewmatrix, dev, "viewmatrix")
+        p = _f32(projmatrix, dev, "projmatrix")
+        with torch.cuda.device(dev):
+            rc = _lib.lib().lr_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr(), _stream(dev))
+        if rc < 0:
+            _lib.raise_for(rc, "mark_visible")
+    return present
+
+
+def check(geomBuffer):
+    """Synchronise and return num_rendered of a forward; raises on async-mode overflow / prefiltered trap."""
+    import ctypes
+    n = ctypes.c_longlong(0)
+    dev = geomBuffer.device
+    with torch.cuda.device(dev):
+        rc = _lib.lib().lr_check(geomBuffer.data_ptr(), ctypes.byref(n), _stream(dev))
+    if rc < 0:
+        _lib.raise_for(rc, "check")
+    return int(n.value)

@@ -1,0 +1,92 @@
+"""ctypes binding of liblucid_raster.so (the C-ABI declared in include/lucid_raster.h).
+
+This is the reference-side binding a maintainer would add in place of the pybind11 module
+`depth_diff_gaussian_rasterization_min._C` (RAST/ext.cpp:15-19).  There is NO CPU fallback: if the
+HIP library is missing this module raises, and tensors that are not on a HIP device are rejected.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblucid_raster.so")
+
+ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
+
+LR_ERR_INVALID_ARG = -10
+LR_ERR_HIP = -11
+LR_ERR_PREFILTERED = -12
+LR_ERR_OVERFLOW = -13
+LR_ERR_ALLOC = -14
+LR_NUM_RENDERED_ON_DEVICE = -1
+
+_lib = None
+_lock = threading.Lock()
+
+EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
+           "lr_backward", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2")
+
+
+def lib():
+    """Load the library (built by `python -m luciddreamer_amd.build` / __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"luciddreamer_amd: HIP library {LIB_PATH} is missing -- build it with "
+                "`python -m luciddreamer_amd.build` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, ci, cf, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
+        L.lr_last_error.restype = ctypes.c_char_p
+        L.lr_last_error.argtypes = []
+        L.lr_version.restype = ctypes.c_char_p
+        L.lr_version.argtypes = []
+        L.lr_geom_bytes.restype = ctypes.c_size_t
+        L.lr_geom_bytes.argtypes = [ci]
+        L.lr_img_bytes.restype = ctypes.c_size_t
+        L.lr_img_bytes.argtypes = [ci, ci]
+        L.lr_binning_bytes.restype = ctypes.c_size_t
+        L.lr_binning_bytes.argtypes = [ll]
+        L.lr_forward.restype = ci
+        L.lr_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp,      # allocators
+                                 ci, ci, ci, vp, ci, ci,                         # P D M bg W H
+                                 vp, vp, vp, vp, vp, cf, vp, vp,                 # means3D shs colors opac scales mod rot cov3D
+                                 vp, vp, vp, cf, cf, ci,                         # view proj campos tanx tany prefiltered
+                                 vp, vp, vp, ci, ll, vp]                         # out_color out_depth radii debug capacity stream
+        L.lr_backward.restype = ci
+        L.lr_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci,                    # P D M R bg W H
+                                  vp, vp, vp, vp, cf, vp, vp,                    # means3D shs colors scales mod rot cov3D
+                                  vp, vp, vp, cf, cf, vp,                        # view proj campos tanx tany radii
+                                  vp, vp, vp, vp, vp,                            # geom binning img dL_dpix dL_ddepth
+                                  vp, vp, vp, vp, vp, vp, vp, vp, vp,            # 9 gradient outputs
+                                  ci, ll, vp]                                    # debug capacity stream
+        L.lr_mark_visible.restype = ci
+        L.lr_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+        L.lr_check.restype = ci
+        L.lr_check.argtypes = [vp, ctypes.POINTER(ll), vp]
+        L.lr_dist2_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_dist2_workspace_bytes.argtypes = [ci]
+        L.lr_dist2.restype = ci
+        L.lr_dist2.argtypes = [ci, vp, vp, vp, vp]
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().lr_last_error().decode("utf-8", "replace")
+
+
+def raise_for(code, where):
+    """Map a negative return code to the exception type the reference raises."""
+    msg = last_error()
+    if code == LR_ERR_INVALID_ARG:
+        raise RuntimeError(f"{where}: {msg}")
+    if code == LR_ERR_PREFILTERED:
+        raise RuntimeError(msg)
+    if code == LR_ERR_OVERFLOW:
+        raise RuntimeError(f"{where}: {msg}")
+    raise RuntimeError(f"{where}: error {code}: {msg}")

@@ -1,0 +1,293 @@
+// api.hip -- extern "C" entry points declared in include/lucid_raster.h (host orchestration).
+//
+// lr_forward  follows CudaRasterizer::Rasterizer::forward  (RAST/cuda_rasterizer/rasterizer_impl.cu:198-339)
+// lr_backward follows CudaRasterizer::Rasterizer::backward (RAST/cuda_rasterizer/rasterizer_impl.cu:343-444)
+// lr_mark_visible follows Rasterizer::markVisible (RAST/cuda_rasterizer/rasterizer_impl.cu:141-153)
+#include "common.h"
+#include "../../include/lucid_raster.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+
+#define LR_HIP_CHECK(expr)                                                                        \
+    do {                                                                                          \
+        hipError_t e__ = (expr);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return fail(LR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));          \
+    } while (0)
+
+// debug => synchronise and surface asynchronous errors (CHECK_CUDA, auxiliary.h:166-173)
+#define LR_DEBUG_SYNC(debug, stream, what)                                                        \
+    do {                                                                                          \
+        if (debug) {                                                                              \
+            hipError_t e__ = hipStreamSynchronize(stream);                                        \
+            if (e__ == hipSuccess) e__ = hipGetLastError();                                       \
+            if (e__ != hipSuccess)                                                                \
+                return fail(LR_ERR_HIP, std::string("[HIP ERROR] after ") + what + ": " + hipGetErrorString(e__)); \
+        }                                                                                         \
+    } while (0)
+
+int bits_for(uint32_t max_value)
+{
+    int b = 0;
+    while (b < 32 && (max_value >> b) != 0) b++;
+    return b < 1 ? 1 : b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* lr_last_error(void) { return g_last_error.c_str(); }
+const char* lr_version(void) { return "luciddreamer_amd-raster 0.1 (gfx950)"; }
+
+size_t lr_geom_bytes(int P) { return lr::geom_layout(P).total; }
+size_t lr_img_bytes(int width, int height) { return lr::img_layout(width, height).total; }
+size_t lr_binning_bytes(long long R) { return lr::bin_layout(R).total; }
+
+int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_alloc, void* binning_user,
+               lr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
+               int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+               const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+               float* out_depth, int* radii, int debug, long long binning_capacity, void* stream_)
+{
+    using namespace lr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0 || width <= 0 || height <= 0) return fail(LR_ERR_INVALID_ARG, "P, width, height must be positive");
+    if (!geom_alloc || !binning_alloc || !img_alloc) return fail(LR_ERR_INVALID_ARG, "allocator callbacks are required");
+    if (!background || !viewmatrix || !projmatrix || !cam_pos || !out_color || !out_depth)
+        return fail(LR_ERR_INVALID_ARG, "background/viewmatrix/projmatrix/cam_pos/out_color/out_depth are required");
+    if (P > 0 && (!means3D || !opacities || !radii)) return fail(LR_ERR_INVALID_ARG, "means3D/opacities/radii are required");
+    if (P > 0 && shs == nullptr && colors_precomp == nullptr)
+        return fail(LR_ERR_INVALID_ARG, "For non-RGB, provide precomputed Gaussian colors!");      // rasterizer_impl.cu:243-246
+    if (P > 0 && cov3D_precomp == nullptr && (scales == nullptr || rotations == nullptr))
+        return fail(LR_ERR_INVALID_ARG, "provide scales+rotations or cov3D_precomp");
+    if (shs != nullptr && (D < 0 || D > 3 || (D + 1) * (D + 1) > M))
+        return fail(LR_ERR_INVALID_ARG, "SH degree must be 0..3 and (D+1)^2 <= M");
+    if (binning_capacity < 0 || binning_capacity > 0xFFFFFFF0ll) return fail(LR_ERR_INVALID_ARG, "bad binning_capacity");
+
+    const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+    const int num_tiles = gx * gy;
+
+    const GeomLayout GL = geom_layout(P);
+    const ImgLayout IL = img_layout(width, height);
+    char* geom = geom_alloc(GL.total, geom_user);
+    char* img = img_alloc(IL.total, img_user);
+    if (!geom || !img) return fail(LR_ERR_ALLOC, "geom/img allocator returned NULL");
+
+    GeomHeader* hdr = reinterpret_cast<GeomHeader*>(geom + GL.header);
+    GaussRec* rec = reinterpret_cast<GaussRec*>(geom + GL.rec);
+    uint8_t* clamped = reinterpret_cast<uint8_t*>(geom + GL.clamped);
+    uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + GL.tiles_touched);
+    uint32_t* gkey_a = reinterpret_cast<uint32_t*>(geom + GL.key_a);
+    uint32_t* gkey_b = reinterpret_cast<uint32_t*>(geom + GL.key_b);
+    uint32_t* gval_a = reinterpret_cast<uint32_t*>(geom + GL.val_a);
+    uint32_t* gval_b = reinterpret_cast<uint32_t*>(geom + GL.val_b);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(geom + GL.offsets);
+    uint32_t* scan_sums = reinterpret_cast<uint32_t*>(geom + GL.scan_sums);
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(geom + GL.hist);
+    float* final_T = reinterpret_cast<float*>(img + IL.final_T);
+    uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + IL.n_contrib);
+    uint2* ranges = reinterpret_cast<uint2*>(img + IL.ranges);
+
+    // header starts zeroed; the preprocess kernel fills in {capacity, P}
+    LR_HIP_CHECK(hipMemsetAsync(hdr, 0, sizeof(GeomHeader), s));
+
+    ViewParams vp;
+    vp.view = viewmatrix; vp.proj = projmatrix; vp.campos = cam_pos;
+    vp.tan_fovx = tan_fovx; vp.tan_fovy = tan_fovy;
+    vp.focal_y = height / (2.0f * tan_fovy);                   // rasterizer_impl.cu:223-224
+    vp.focal_x = width / (2.0f * tan_fovx);
+    vp.scale_modifier = scale_modifier;
+    vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
+
+    long long R_bound = 0;
+    int num_rendered = 0;
+    uint32_t* point_list = nullptr;
+    uint32_t* inst_keys_sorted = nullptr;
+    // which ping-pong half ends up holding the tile-sorted list: a pure function of the tile count
+    const int tile_bits = bits_for((uint32_t)(num_tiles - 1));
+    const int tile_passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
+
+    if (P > 0) {
+        // K1: cull / project / conic / colour -> GaussRec, radii, tile counts, depth keys
+        launch_preprocess(vp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
+                          prefiltered != 0, radii, rec, clamped, tiles_touched, gkey_a, hdr,
+                          (uint32_t)binning_capacity, s);
+        LR_DEBUG_SYNC(debug, s, "preprocess");
+
+        // depth order of the Gaussians (stable, value = index); culled ones (key 0xFFFFFFFF) go last
+        uint32_t *sorted_depth_keys, *order;
+        radix_sort_pairs(gkey_a, gkey_b, gval_a, gval_b, /*iota*/ true, &hdr->P, P, 32, ghist, &sorted_depth_keys,
+                         &order, s);
+        (void)sorted_depth_keys;
+        LR_DEBUG_SYNC(debug, s, "depth sort");
+
+        // exclusive scan of tile counts in depth order; total -> header
+        launch_scan_tiles(P, order, tiles_touched, offsets, scan_sums, hdr, s);
+        LR_DEBUG_SYNC(debug, s, "scan");
+
+        if (binning_capacity == 0) {
+            // exact mode: one 4-byte read-back, like rasterizer_impl.cu:281-282
+            uint32_t hostR = 0;
+            LR_HIP_CHECK(hipMemcpyAsync(&hostR, &hdr->num_rendered, 4, hipMemcpyDeviceToHost, s));
+            LR_HIP_CHECK(hipStreamSynchronize(s));
+            R_bound = hostR;
+            num_rendered = (int)hostR;
+        } else {
+            R_bound = binning_capacity;
+            num_rendered = LR_NUM_RENDERED_ON_DEVICE;
+        }
+
+        const BinLayout BL = bin_layout(R_bound);
+        char* bin = binning_alloc(BL.total, binning_user);
+        if (!bin) return fail(LR_ERR_ALLOC, "binning allocator returned NULL");
+        uint32_t* bkey_a = reinterpret_cast<uint32_t*>(bin + BL.key_a);
+        uint32_t* bkey_b = reinterpret_cast<uint32_t*>(bin + BL.key_b);
+        uint32_t* bval_a = reinterpret_cast<uint32_t*>(bin + BL.val_a);
+        uint32_t* bval_b = reinterpret_cast<uint32_t*>(bin + BL.val_b);
+        uint32_t* bhist = reinterpret_cast<uint32_t*>(bin + BL.hist);
+
+        if (R_bound > 0) {
+            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, bkey_a, bval_a, s);
+            LR_DEBUG_SYNC(debug, s, "emit");
+            // stable partition by tile id: with the depth order of emission this is the reference's
+            // (tile | depth) order (rasterizer_impl.cu:301-309)
+            radix_sort_pairs(bkey_a, bkey_b, bval_a, bval_b, /*iota*/ false, &hdr->num_sorted, R_bound, tile_bits,
+                             bhist, &inst_keys_sorted, &point_list, s);
+            LR_DEBUG_SYNC(debug, s, "tile sort");
+        } else {
+            inst_keys_sorted = (tile_passes & 1) ? bkey_b : bkey_a;
+            point_list = (tile_passes & 1) ? bval_b : bval_a;
+        }
+        launch_ranges(inst_keys_sorted, hdr, R_bound, num_tiles, ranges, s);
+        LR_DEBUG_SYNC(debug, s, "ranges");
+    } else {
+        (void)binning_alloc(bin_layout(0).total, binning_user);
+        LR_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)num_tiles * sizeof(uint2), s));
+    }
+
+    // K6: blend
+    launch_render_fwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, out_color,
+                      out_depth, s);
+    LR_DEBUG_SYNC(debug, s, "render");
+    LR_HIP_CHECK(hipGetLastError());
+
+    if (binning_capacity == 0 && prefiltered && P > 0) {
+        uint32_t trap = 0;
+        LR_HIP_CHECK(hipMemcpyAsync(&trap, &hdr->prefilter_trap, 4, hipMemcpyDeviceToHost, s));
+        LR_HIP_CHECK(hipStreamSynchronize(s));
+        if (trap) return fail(LR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    }
+    return num_rendered;
+}
+
+int lr_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
+                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                float* dL_dscale, float* dL_drot, int debug, long long binning_capacity, void* stream_)
+{
+    using namespace lr;
+    (void)dL_depths;   // ignored, as in the reference (backward.cu:457-464, 539-554 commented out)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (P <= 0) return 0;
+    if (!geom_buffer || !binning_buffer || !image_buffer) return fail(LR_ERR_INVALID_ARG, "scratch buffers are required");
+    if (!dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(LR_ERR_INVALID_ARG, "gradient outputs are required");
+    if (shs != nullptr && dL_dsh == nullptr) return fail(LR_ERR_INVALID_ARG, "dL_dsh is required when shs is given");
+
+    const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
+    const GeomLayout GL = geom_layout(P);
+    const ImgLayout IL = img_layout(width, height);
+    const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom_buffer + GL.rec);
+    const uint8_t* clamped = reinterpret_cast<const uint8_t*>(geom_buffer + GL.clamped);
+    GradRec* grad = reinterpret_cast<GradRec*>(geom_buffer + GL.grad);
+    const float* final_T = reinterpret_cast<const float*>(image_buffer + IL.final_T);
+    const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + IL.n_contrib);
+    const uint2* ranges = reinterpret_cast<const uint2*>(image_buffer + IL.ranges);
+
+    // The binning layout is a function of the size the forward allocated for: R (exact mode) or
+    // binning_capacity (async mode); the ping-pong half holding the final list depends only on the
+    // number of tile-sort passes.  No device read-back is needed here.
+    if (binning_capacity <= 0 && R < 0) return fail(LR_ERR_INVALID_ARG, "pass R (exact mode) or binning_capacity (async mode)");
+    const long long R_bound = binning_capacity > 0 ? binning_capacity : (long long)R;
+    const int tile_bits = bits_for((uint32_t)(gx * gy - 1));
+    const uint32_t which = (uint32_t)(((tile_bits + RADIX_BITS - 1) / RADIX_BITS) & 1);
+    const BinLayout BL = bin_layout(R_bound);
+    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + (which ? BL.val_b : BL.val_a));
+
+    ViewParams vp;
+    vp.view = viewmatrix; vp.proj = projmatrix; vp.campos = campos;
+    vp.tan_fovx = tan_fovx; vp.tan_fovy = tan_fovy;
+    vp.focal_y = height / (2.0f * tan_fovy);
+    vp.focal_x = width / (2.0f * tan_fovx);
+    vp.scale_modifier = scale_modifier;
+    vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
+
+    LR_HIP_CHECK(hipMemsetAsync(grad, 0, (size_t)P * sizeof(GradRec), s));
+    launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix, grad, s);
+    LR_DEBUG_SYNC(debug, s, "render backward");
+    launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, grad,
+                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                     dL_drot, s);
+    LR_DEBUG_SYNC(debug, s, "preprocess backward");
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                    unsigned char* present, void* stream_)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0) return fail(LR_ERR_INVALID_ARG, "P must be >= 0");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !projmatrix || !present) return fail(LR_ERR_INVALID_ARG, "NULL argument");
+    lr::launch_mark_visible(P, means3D, viewmatrix, projmatrix, present, s);
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int lr_check(const char* geom_buffer, long long* num_rendered, void* stream_)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!geom_buffer) return fail(LR_ERR_INVALID_ARG, "NULL geom buffer");
+    uint32_t meta[8];
+    LR_HIP_CHECK(hipMemcpyAsync(meta, geom_buffer, sizeof(meta), hipMemcpyDeviceToHost, s));
+    LR_HIP_CHECK(hipStreamSynchronize(s));
+    if (num_rendered) *num_rendered = meta[0];
+    if (meta[2]) return fail(LR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    if (meta[1]) return fail(LR_ERR_OVERFLOW, "binning capacity exceeded");
+    return 0;
+}
+
+size_t lr_dist2_workspace_bytes(int P) { return lr::dist2_workspace_bytes(P); }
+
+int lr_dist2(int P, const float* points, float* out, char* workspace, void* stream_)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (P < 0) return fail(LR_ERR_INVALID_ARG, "P must be >= 0");
+    if (P == 0) return 0;
+    if (!points || !out || !workspace) return fail(LR_ERR_INVALID_ARG, "NULL argument");
+    lr::launch_dist2(P, points, out, workspace, s);
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,330 @@
+// gauss_bwd.hip -- per-Gaussian backward stage for gfx950.
+//
+// Replaces computeCov2DCUDA (RAST/cuda_rasterizer/backward.cu:144-274) and the backward
+// preprocessCUDA (:346-396) with its helpers computeColorFromSH (:20-139) and computeCov3D
+// (:278-341) -- fused into ONE streaming pass: read the 48-byte GradRec produced by the blend
+// backward, recompute the forward intermediates from the inputs (cheaper than storing cov3D /
+// re-reading it: HBM-bound kernel), and write every gradient row exactly once.  Rows of culled
+// Gaussians are written as zeros here, so the caller never has to zero-fill the nine output
+// tensors (the reference memsets 300 B/Gaussian per backward, rasterize_points.cu:154-162).
+#include "common.h"
+
+namespace lr {
+
+namespace {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                        -1.0925484305920792f, 0.5462742152960396f };
+__device__ constexpr float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                        0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                        -0.5900435899266435f };
+
+struct M3 { float c[3][3]; };   // column-major like glm::mat3: c[col][row]
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) R.c[j][i] = A.c[i][j];
+    return R;
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+// Row store of `n` floats at dst (n*4 bytes per row).  Uses 16-byte stores when the row is aligned.
+template <int NMAX>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float (&v)[NMAX], int n)
+{
+    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+#pragma unroll
+        for (int q = 0; q < NMAX / 4; q++)
+            if (4 * q < n) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < NMAX; q++)
+            if (q < n) dst[q] = v[q];
+    }
+}
+
+// SH backward for one Gaussian (backward.cu:20-139).  Fills dsh[0..3K) and returns dL/ddir.
+template <int DEG>
+__device__ __forceinline__ V3 sh_backward(const float* __restrict__ sh_row, V3 dir, V3 dL_dRGB, float (&dsh)[48])
+{
+    constexpr int K = (DEG + 1) * (DEG + 1);
+    V3 sh[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) sh[k] = { sh_row[3 * k], sh_row[3 * k + 1], sh_row[3 * k + 2] };
+    float basis[K];
+    const float x = dir.x, y = dir.y, z = dir.z;
+    V3 dRGBdx = { 0, 0, 0 }, dRGBdy = { 0, 0, 0 }, dRGBdz = { 0, 0, 0 };
+    basis[0] = SH_C0;
+    if (DEG > 0) {
+        basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
+        dRGBdx = -SH_C1 * sh[3];
+        dRGBdy = -SH_C1 * sh[1];
+        dRGBdz = SH_C1 * sh[2];
+        if (DEG > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2.f * zz - xx - yy);
+            basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
+            dRGBdx = dRGBdx + ((SH_C2[0] * y) * sh[4] + (SH_C2[2] * 2.f * -x) * sh[6] + (SH_C2[3] * z) * sh[7] + (SH_C2[4] * 2.f * x) * sh[8]);
+            dRGBdy = dRGBdy + ((SH_C2[0] * x) * sh[4] + (SH_C2[1] * z) * sh[5] + (SH_C2[2] * 2.f * -y) * sh[6] + (SH_C2[4] * 2.f * -y) * sh[8]);
+            dRGBdz = dRGBdz + ((SH_C2[1] * y) * sh[5] + (SH_C2[2] * 2.f * 2.f * z) * sh[6] + (SH_C2[3] * x) * sh[7]);
+            if (DEG > 2) {
+                basis[9] = SH_C3[0] * y * (3.f * xx - yy);
+                basis[10] = SH_C3[1] * xy * z;
+                basis[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                basis[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                basis[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                basis[14] = SH_C3[5] * z * (xx - yy);
+                basis[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                dRGBdx = dRGBdx + ((SH_C3[0] * 3.f * 2.f * xy) * sh[9] + (SH_C3[1] * yz) * sh[10] + (SH_C3[2] * -2.f * xy) * sh[11]
+                                   + (SH_C3[3] * -3.f * 2.f * xz) * sh[12] + (SH_C3[4] * (-3.f * xx + 4.f * zz - yy)) * sh[13]
+                                   + (SH_C3[5] * 2.f * xz) * sh[14] + (SH_C3[6] * 3.f * (xx - yy)) * sh[15]);
+                dRGBdy = dRGBdy + ((SH_C3[0] * 3.f * (xx - yy)) * sh[9] + (SH_C3[1] * xz) * sh[10]
+                                   + (SH_C3[2] * (-3.f * yy + 4.f * zz - xx)) * sh[11] + (SH_C3[3] * -3.f * 2.f * yz) * sh[12]
+                                   + (SH_C3[4] * -2.f * xy) * sh[13] + (SH_C3[5] * -2.f * yz) * sh[14]
+                                   + (SH_C3[6] * -3.f * 2.f * xy) * sh[15]);
+                dRGBdz = dRGBdz + ((SH_C3[1] * xy) * sh[10] + (SH_C3[2] * 4.f * 2.f * yz) * sh[11]
+                                   + (SH_C3[3] * 3.f * (2.f * zz - xx - yy)) * sh[12] + (SH_C3[4] * 4.f * 2.f * xz) * sh[13]
+                                   + (SH_C3[5] * (xx - yy)) * sh[14]);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        dsh[3 * k] = basis[k] * dL_dRGB.x; dsh[3 * k + 1] = basis[k] * dL_dRGB.y; dsh[3 * k + 2] = basis[k] * dL_dRGB.z;
+    }
+    return { dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB) };
+}
+
+__global__ void __launch_bounds__(256)
+k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
+            const float* __restrict__ rotations, const float* __restrict__ shs,
+            const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
+            const uint8_t* __restrict__ clamped, const GradRec* __restrict__ grad,
+            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= vp.P) return;
+    const size_t i = (size_t)idx;
+    const float* __restrict__ V = vp.view;
+    const float* __restrict__ Pm = vp.proj;
+    const int shrow = vp.M * 3;
+
+    float o_m2d[3] = { 0, 0, 0 }, o_col[3] = { 0, 0, 0 }, o_m3d[3] = { 0, 0, 0 }, o_scale[3] = { 0, 0, 0 };
+    float o_conic[4] = { 0, 0, 0, 0 }, o_rot[4] = { 0, 0, 0, 0 };
+    float o_cov[6] = { 0, 0, 0, 0, 0, 0 };
+    float o_op = 0.f;
+    float dsh[48];
+#pragma unroll
+    for (int k = 0; k < 48; k++) dsh[k] = 0.f;
+
+    if (radii[idx] > 0) {
+        const float4* gp = reinterpret_cast<const float4*>(grad + i);
+        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
+        const float gmx = g0.x, gmy = g0.y;                 // dL/dmean2D
+        const float gca = g0.z, gcb = g0.w, gcc = g1.x;     // dL/dconic (x, y, w)
+        o_op = g1.y;
+        o_col[0] = g1.z; o_col[1] = g1.w; o_col[2] = g2.x;
+        o_m2d[0] = gmx; o_m2d[1] = gmy;
+        o_conic[0] = gca; o_conic[1] = gcb; o_conic[3] = gcc;
+
+        const float mx = means3D[3 * i], my = means3D[3 * i + 1], mz = means3D[3 * i + 2];
+
+        // ---- recompute cov3D (forward.cu:118-152) ----
+        float c3[6];
+        float sx = 0, sy = 0, sz = 0, qr = 0, qx = 0, qy = 0, qz = 0;
+        M3 Rm = {}, Mm = {};
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
+        } else {
+            sx = vp.scale_modifier * scales[3 * i]; sy = vp.scale_modifier * scales[3 * i + 1];
+            sz = vp.scale_modifier * scales[3 * i + 2];
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            M3 S = { { { sx, 0, 0 }, { 0, sy, 0 }, { 0, 0, sz } } };
+            Rm = { { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qr * qz), 2.f * (qx * qz + qr * qy) },
+                     { 2.f * (qx * qy + qr * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qr * qx) },
+                     { 2.f * (qx * qz - qr * qy), 2.f * (qy * qz + qr * qx), 1.f - 2.f * (qx * qx + qy * qy) } } };
+            Mm = m3_mul(S, Rm);
+            M3 Sig = m3_mul(m3_t(Mm), Mm);
+            c3[0] = Sig.c[0][0]; c3[1] = Sig.c[0][1]; c3[2] = Sig.c[0][2];
+            c3[3] = Sig.c[1][1]; c3[4] = Sig.c[1][2]; c3[5] = Sig.c[2][2];
+        }
+
+        // ---- K8: conic gradient -> cov3D gradient and mean gradient (backward.cu:159-273) ----
+        const float vx = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+        const float vy = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+        const float vz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+        const float limx = 1.3f * vp.tan_fovx, limy = 1.3f * vp.tan_fovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float h_x = vp.focal_x, h_y = vp.focal_y;
+        M3 J = { { { h_x / vz, 0.0f, -(h_x * tx) / (vz * vz) },
+                   { 0.0f, h_y / vz, -(h_y * ty) / (vz * vz) },
+                   { 0, 0, 0 } } };
+        M3 Wm = { { { V[0], V[4], V[8] }, { V[1], V[5], V[9] }, { V[2], V[6], V[10] } } };
+        M3 Vrk = { { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } } };
+        M3 T = m3_mul(Wm, J);
+        M3 cov2D = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+        const float a = cov2D.c[0][0] + 0.3f, b = cov2D.c[0][1], c = cov2D.c[1][1] + 0.3f;
+        const float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * gca + 2 * b * c * gcb + (denom - a * c) * gcc);
+            dL_dc = denom2inv * (-a * a * gcc + 2 * a * b * gcb + (denom - a * c) * gca);
+            dL_db = denom2inv * 2 * (b * c * gca - (denom + 2 * b * b) * gcb + a * b * gcc);
+            o_cov[0] = (T.c[0][0] * T.c[0][0] * dL_da + T.c[0][0] * T.c[1][0] * dL_db + T.c[1][0] * T.c[1][0] * dL_dc);
+            o_cov[3] = (T.c[0][1] * T.c[0][1] * dL_da + T.c[0][1] * T.c[1][1] * dL_db + T.c[1][1] * T.c[1][1] * dL_dc);
+            o_cov[5] = (T.c[0][2] * T.c[0][2] * dL_da + T.c[0][2] * T.c[1][2] * dL_db + T.c[1][2] * T.c[1][2] * dL_dc);
+            o_cov[1] = 2 * T.c[0][0] * T.c[0][1] * dL_da + (T.c[0][0] * T.c[1][1] + T.c[0][1] * T.c[1][0]) * dL_db + 2 * T.c[1][0] * T.c[1][1] * dL_dc;
+            o_cov[2] = 2 * T.c[0][0] * T.c[0][2] * dL_da + (T.c[0][0] * T.c[1][2] + T.c[0][2] * T.c[1][0]) * dL_db + 2 * T.c[1][0] * T.c[1][2] * dL_dc;
+            o_cov[4] = 2 * T.c[0][2] * T.c[0][1] * dL_da + (T.c[0][1] * T.c[1][2] + T.c[0][2] * T.c[1][1]) * dL_db + 2 * T.c[1][1] * T.c[1][2] * dL_dc;
+        }
+        // dL/dT (upper 2x3), dL/dJ, dL/dt
+        float tv0[3], tv1[3];   // T[0][k]*Vrk[j][k] sums
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            tv0[j] = T.c[0][0] * Vrk.c[j][0] + T.c[0][1] * Vrk.c[j][1] + T.c[0][2] * Vrk.c[j][2];
+            tv1[j] = T.c[1][0] * Vrk.c[j][0] + T.c[1][1] * Vrk.c[j][1] + T.c[1][2] * Vrk.c[j][2];
+        }
+        const float dL_dT00 = 2 * tv0[0] * dL_da + tv1[0] * dL_db;
+        const float dL_dT01 = 2 * tv0[1] * dL_da + tv1[1] * dL_db;
+        const float dL_dT02 = 2 * tv0[2] * dL_da + tv1[2] * dL_db;
+        const float dL_dT10 = 2 * tv1[0] * dL_dc + tv0[0] * dL_db;
+        const float dL_dT11 = 2 * tv1[1] * dL_dc + tv0[1] * dL_db;
+        const float dL_dT12 = 2 * tv1[2] * dL_dc + tv0[2] * dL_db;
+        const float dL_dJ00 = Wm.c[0][0] * dL_dT00 + Wm.c[0][1] * dL_dT01 + Wm.c[0][2] * dL_dT02;
+        const float dL_dJ02 = Wm.c[2][0] * dL_dT00 + Wm.c[2][1] * dL_dT01 + Wm.c[2][2] * dL_dT02;
+        const float dL_dJ11 = Wm.c[1][0] * dL_dT10 + Wm.c[1][1] * dL_dT11 + Wm.c[1][2] * dL_dT12;
+        const float dL_dJ12 = Wm.c[2][0] * dL_dT10 + Wm.c[2][1] * dL_dT11 + Wm.c[2][2] * dL_dT12;
+        const float tz = 1.f / vz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -h_x * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -h_y * tz2 * dL_dJ12;
+        const float dL_dtz = -h_x * tz2 * dL_dJ00 - h_y * tz2 * dL_dJ11 + (2 * h_x * tx) * tz3 * dL_dJ02 + (2 * h_y * ty) * tz3 * dL_dJ12;
+        // transformVec4x3Transpose (auxiliary.h:89-97); assigned, not accumulated (backward.cu:273)
+        o_m3d[0] = V[0] * dL_dtx + V[1] * dL_dty + V[2] * dL_dtz;
+        o_m3d[1] = V[4] * dL_dtx + V[5] * dL_dty + V[6] * dL_dtz;
+        o_m3d[2] = V[8] * dL_dtx + V[9] * dL_dty + V[10] * dL_dtz;
+
+        // ---- K9: screen-space mean gradient through the projection (backward.cu:370-387) ----
+        const float hw = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+        const float m_w = 1.0f / (hw + 0.0000001f);
+        const float mul1 = (Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12]) * m_w * m_w;
+        const float mul2 = (Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13]) * m_w * m_w;
+        o_m3d[0] += (Pm[0] * m_w - Pm[3] * mul1) * gmx + (Pm[1] * m_w - Pm[3] * mul2) * gmy;
+        o_m3d[1] += (Pm[4] * m_w - Pm[7] * mul1) * gmx + (Pm[5] * m_w - Pm[7] * mul2) * gmy;
+        o_m3d[2] += (Pm[8] * m_w - Pm[11] * mul1) * gmx + (Pm[9] * m_w - Pm[11] * mul2) * gmy;
+
+        // ---- SH backward (backward.cu:20-139) ----
+        if (shs != nullptr) {
+            const V3 dir_orig = { mx - vp.campos[0], my - vp.campos[1], mz - vp.campos[2] };
+            const float len = sqrtf(dot(dir_orig, dir_orig));
+            const V3 dir = { dir_orig.x / len, dir_orig.y / len, dir_orig.z / len };
+            const uint8_t cb = clamped[idx];
+            const V3 dL_dRGB = { (cb & 1) ? 0.f : o_col[0], (cb & 2) ? 0.f : o_col[1], (cb & 4) ? 0.f : o_col[2] };
+            const float* sh_row = shs + i * shrow;
+            V3 dL_ddir;
+            switch (vp.D) {
+                case 0: dL_ddir = sh_backward<0>(sh_row, dir, dL_dRGB, dsh); break;
+                case 1: dL_ddir = sh_backward<1>(sh_row, dir, dL_dRGB, dsh); break;
+                case 2: dL_ddir = sh_backward<2>(sh_row, dir, dL_dRGB, dsh); break;
+                default: dL_ddir = sh_backward<3>(sh_row, dir, dL_dRGB, dsh); break;
+            }
+            // dnormvdv (auxiliary.h:107-117)
+            const V3 v = dir_orig, dv = dL_ddir;
+            const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+            const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+            o_m3d[0] += ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+            o_m3d[1] += (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+            o_m3d[2] += (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+        }
+
+        // ---- cov3D -> scale / rotation (backward.cu:278-341) ----
+        if (scales != nullptr) {
+            M3 dSig = { { { o_cov[0], 0.5f * o_cov[1], 0.5f * o_cov[2] },
+                          { 0.5f * o_cov[1], o_cov[3], 0.5f * o_cov[4] },
+                          { 0.5f * o_cov[2], 0.5f * o_cov[4], o_cov[5] } } };
+            M3 M2 = Mm;
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) M2.c[j][k] = 2.0f * Mm.c[j][k];
+            M3 dL_dM = m3_mul(M2, dSig);
+            M3 Rt = m3_t(Rm);
+            M3 dMt = m3_t(dL_dM);
+            o_scale[0] = Rt.c[0][0] * dMt.c[0][0] + Rt.c[0][1] * dMt.c[0][1] + Rt.c[0][2] * dMt.c[0][2];
+            o_scale[1] = Rt.c[1][0] * dMt.c[1][0] + Rt.c[1][1] * dMt.c[1][1] + Rt.c[1][2] * dMt.c[1][2];
+            o_scale[2] = Rt.c[2][0] * dMt.c[2][0] + Rt.c[2][1] * dMt.c[2][1] + Rt.c[2][2] * dMt.c[2][2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { dMt.c[0][k] *= sx; dMt.c[1][k] *= sy; dMt.c[2][k] *= sz; }
+#define Q(a_, b_) dMt.c[a_][b_]
+            o_rot[0] = 2 * qz * (Q(0, 1) - Q(1, 0)) + 2 * qy * (Q(2, 0) - Q(0, 2)) + 2 * qx * (Q(1, 2) - Q(2, 1));
+            o_rot[1] = 2 * qy * (Q(1, 0) + Q(0, 1)) + 2 * qz * (Q(2, 0) + Q(0, 2)) + 2 * qr * (Q(1, 2) - Q(2, 1)) - 4 * qx * (Q(2, 2) + Q(1, 1));
+            o_rot[2] = 2 * qx * (Q(1, 0) + Q(0, 1)) + 2 * qr * (Q(2, 0) - Q(0, 2)) + 2 * qz * (Q(1, 2) + Q(2, 1)) - 4 * qy * (Q(2, 2) + Q(0, 0));
+            o_rot[3] = 2 * qr * (Q(0, 1) - Q(1, 0)) + 2 * qx * (Q(2, 0) + Q(0, 2)) + 2 * qy * (Q(1, 2) + Q(2, 1)) - 4 * qz * (Q(1, 1) + Q(0, 0));
+#undef Q
+        }
+    }
+
+    // ---- write every row exactly once ----
+    dL_dmean2D[3 * i] = o_m2d[0]; dL_dmean2D[3 * i + 1] = o_m2d[1]; dL_dmean2D[3 * i + 2] = 0.f;
+    if (dL_dconic != nullptr)
+        reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(o_conic[0], o_conic[1], 0.f, o_conic[3]);
+    dL_dopacity[idx] = o_op;
+    dL_dcolor[3 * i] = o_col[0]; dL_dcolor[3 * i + 1] = o_col[1]; dL_dcolor[3 * i + 2] = o_col[2];
+    dL_dmean3D[3 * i] = o_m3d[0]; dL_dmean3D[3 * i + 1] = o_m3d[1]; dL_dmean3D[3 * i + 2] = o_m3d[2];
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = o_cov[k];
+    dL_dscale[3 * i] = o_scale[0]; dL_dscale[3 * i + 1] = o_scale[1]; dL_dscale[3 * i + 2] = o_scale[2];
+    reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+    if (dL_dsh != nullptr && shrow > 0) {
+        if (shrow <= 48) store_row<48>(dL_dsh + i * shrow, dsh, shrow);
+        else {
+            float* dst = dL_dsh + i * shrow;
+            for (int k = 0; k < shrow; k++) dst[k] = (k < 48) ? dsh[k] : 0.f;
+        }
+    }
+}
+
+}  // namespace
+
+void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
+                      const float* shs, const float* cov3D_precomp, const float* colors_precomp,
+                      const int* radii, const uint8_t* clamped, const GradRec* grad,
+                      float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                      float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                      hipStream_t s)
+{
+    (void)colors_precomp;
+    if (vp.P <= 0) return;
+    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + 255) / 256), dim3(256), 0, s, vp, means3D, scales, rotations, shs,
+                       cov3D_precomp, radii, clamped, grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+}
+
+}  // namespace lr

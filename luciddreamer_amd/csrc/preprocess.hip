@@ -1,0 +1,284 @@
+// preprocess.hip -- per-Gaussian forward stage for gfx950.
+//
+// Replaces FORWARD::preprocess / preprocessCUDA (RAST/cuda_rasterizer/forward.cu:155-256) and
+// checkFrustum (RAST/cuda_rasterizer/rasterizer_impl.cu:54-66).  One streaming pass over the
+// Gaussian attribute arrays: frustum cull, projection, 3D->2D covariance (EWA), conic, radius,
+// tile rectangle, SH->RGB; output is ONE packed 48-byte GaussRec per Gaussian plus the depth sort
+// key -- the reference scatters the same data over seven arrays.
+//
+// This translation unit is compiled with -ffp-contract=off: every product/sum is rounded in the
+// operand order the reference source uses (GLM column-major operator order), so that radii, tile
+// rectangles, depths and conics are bit-identical to the CPU oracle and the discrete outputs
+// (radii, num_rendered, per-tile order) can be compared exactly.  The kernel is HBM-bound, so the
+// missing FMAs cost nothing.
+#include "common.h"
+
+namespace lr {
+
+namespace {
+
+__device__ constexpr float SH_C0 = 0.28209479177387814f;
+__device__ constexpr float SH_C1 = 0.4886025119029199f;
+__device__ constexpr float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                        -1.0925484305920792f, 0.5462742152960396f };
+__device__ constexpr float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                        0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                        -0.5900435899266435f };
+
+struct M3 { float c[3][3]; };   // column-major like glm::mat3: c[col][row]
+
+__device__ __forceinline__ M3 m3_mul(const M3& A, const M3& B)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            R.c[j][i] = A.c[0][i] * B.c[j][0] + A.c[1][i] * B.c[j][1] + A.c[2][i] * B.c[j][2];
+    return R;
+}
+__device__ __forceinline__ M3 m3_t(const M3& A)
+{
+    M3 R;
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) R.c[j][i] = A.c[i][j];
+    return R;
+}
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 sh_fma(V3 acc, float s, const V3& c, bool sub = false)
+{
+    // acc (+|-) s * c, each product rounded separately (contraction is off in this TU)
+    V3 r;
+    if (sub) { r.x = acc.x - s * c.x; r.y = acc.y - s * c.y; r.z = acc.z - s * c.z; }
+    else     { r.x = acc.x + s * c.x; r.y = acc.y + s * c.y; r.z = acc.z + s * c.z; }
+    return r;
+}
+
+// Load K coefficient triples of Gaussian idx.  M==16 rows are 192 B (16-byte aligned): 12 x dwordx4.
+template <int K>
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t idx, int M, V3 (&sh)[16])
+{
+    const float* base = shs + idx * (size_t)M * 3;
+    constexpr int NF = 3 * K;
+    float f[(NF + 3) / 4 * 4];
+    if (((M * 3) & 3) == 0 && ((reinterpret_cast<uintptr_t>(shs) & 15) == 0)) {
+        const float4* b4 = reinterpret_cast<const float4*>(base);
+#pragma unroll
+        for (int q = 0; q < (NF + 3) / 4; q++) {
+            float4 v = b4[q];
+            f[4 * q] = v.x; f[4 * q + 1] = v.y; f[4 * q + 2] = v.z; f[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NF; q++) f[q] = base[q];
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) { sh[k].x = f[3 * k]; sh[k].y = f[3 * k + 1]; sh[k].z = f[3 * k + 2]; }
+}
+
+template <int DEG>
+__device__ __forceinline__ V3 eval_sh(const float* __restrict__ shs, size_t idx, int M, V3 dir, uint8_t& clamp_bits)
+{
+    V3 sh[16];
+    load_sh<(DEG + 1) * (DEG + 1)>(shs, idx, M, sh);
+    V3 res = { SH_C0 * sh[0].x, SH_C0 * sh[0].y, SH_C0 * sh[0].z };
+    if (DEG > 0) {
+        float x = dir.x, y = dir.y, z = dir.z;
+        res = sh_fma(res, SH_C1 * y, sh[1], true);
+        res = sh_fma(res, SH_C1 * z, sh[2]);
+        res = sh_fma(res, SH_C1 * x, sh[3], true);
+        if (DEG > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            res = sh_fma(res, SH_C2[0] * xy, sh[4]);
+            res = sh_fma(res, SH_C2[1] * yz, sh[5]);
+            res = sh_fma(res, SH_C2[2] * (2.0f * zz - xx - yy), sh[6]);
+            res = sh_fma(res, SH_C2[3] * xz, sh[7]);
+            res = sh_fma(res, SH_C2[4] * (xx - yy), sh[8]);
+            if (DEG > 2) {
+                res = sh_fma(res, SH_C3[0] * y * (3.0f * xx - yy), sh[9]);
+                res = sh_fma(res, SH_C3[1] * xy * z, sh[10]);
+                res = sh_fma(res, SH_C3[2] * y * (4.0f * zz - xx - yy), sh[11]);
+                res = sh_fma(res, SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), sh[12]);
+                res = sh_fma(res, SH_C3[4] * x * (4.0f * zz - xx - yy), sh[13]);
+                res = sh_fma(res, SH_C3[5] * z * (xx - yy), sh[14]);
+                res = sh_fma(res, SH_C3[6] * x * (xx - 3.0f * yy), sh[15]);
+            }
+        }
+    }
+    res.x += 0.5f; res.y += 0.5f; res.z += 0.5f;
+    clamp_bits = (uint8_t)((res.x < 0 ? 1 : 0) | (res.y < 0 ? 2 : 0) | (res.z < 0 ? 4 : 0));
+    res.x = fmaxf(res.x, 0.0f); res.y = fmaxf(res.y, 0.0f); res.z = fmaxf(res.z, 0.0f);
+    return res;
+}
+
+// Tile rectangle of a splat (RAST/cuda_rasterizer/auxiliary.h:46-56).
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy,
+                                          int& minx, int& miny, int& maxx, int& maxy)
+{
+    minx = min(gx, max(0, (int)((px - radius) / TILE_X)));
+    miny = min(gy, max(0, (int)((py - radius) / TILE_Y)));
+    maxx = min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
+    maxy = min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
+}
+
+__global__ void __launch_bounds__(256)
+k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
+             const float* __restrict__ rotations, const float* __restrict__ opacities,
+             const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
+             const float* __restrict__ colors_precomp, int prefiltered,
+             int* __restrict__ radii, GaussRec* __restrict__ rec, uint8_t* __restrict__ clamped,
+             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, GeomHeader* hdr,
+             uint32_t binning_capacity)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= vp.P) return;
+    if (idx == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
+    const float* __restrict__ V = vp.view;
+    const float* __restrict__ Pm = vp.proj;
+
+    int radius_out = 0;
+    uint32_t tiles_out = 0;
+    uint32_t key_out = 0xFFFFFFFFu;       // culled Gaussians sort to the end and emit nothing
+
+    const float px_w = means3D[3 * (size_t)idx], py_w = means3D[3 * (size_t)idx + 1], pz_w = means3D[3 * (size_t)idx + 2];
+    // view-space point (auxiliary.h:58-66) and the near cull z <= 0.2 (auxiliary.h:152-162)
+    const float vx = V[0] * px_w + V[4] * py_w + V[8] * pz_w + V[12];
+    const float vy = V[1] * px_w + V[5] * py_w + V[9] * pz_w + V[13];
+    const float vz = V[2] * px_w + V[6] * py_w + V[10] * pz_w + V[14];
+
+    do {
+        if (vz <= 0.2f) {
+            if (prefiltered) hdr->prefilter_trap = 1;
+            break;
+        }
+        // clip-space projection (forward.cu:196-200)
+        const float hx = Pm[0] * px_w + Pm[4] * py_w + Pm[8] * pz_w + Pm[12];
+        const float hy = Pm[1] * px_w + Pm[5] * py_w + Pm[9] * pz_w + Pm[13];
+        const float hw = Pm[3] * px_w + Pm[7] * py_w + Pm[11] * pz_w + Pm[15];
+        const float p_w = 1.0f / (hw + 0.0000001f);
+        const float ndcx = hx * p_w, ndcy = hy * p_w;
+
+        // 3D covariance (forward.cu:118-152), quaternion used as given
+        float c3[6];
+        if (cov3D_precomp != nullptr) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)idx + i];
+        } else {
+            const float sx = scales[3 * (size_t)idx], sy = scales[3 * (size_t)idx + 1], sz = scales[3 * (size_t)idx + 2];
+            const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            M3 S = { { { vp.scale_modifier * sx, 0, 0 }, { 0, vp.scale_modifier * sy, 0 }, { 0, 0, vp.scale_modifier * sz } } };
+            M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
+                       { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
+                       { 2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y) } } };
+            M3 Mm = m3_mul(S, R);
+            M3 Sig = m3_mul(m3_t(Mm), Mm);
+            c3[0] = Sig.c[0][0]; c3[1] = Sig.c[0][1]; c3[2] = Sig.c[0][2];
+            c3[3] = Sig.c[1][1]; c3[4] = Sig.c[1][2]; c3[5] = Sig.c[2][2];
+        }
+
+        // EWA 2D covariance (forward.cu:74-113)
+        const float limx = 1.3f * vp.tan_fovx, limy = 1.3f * vp.tan_fovy;
+        const float txtz = vx / vz, tytz = vy / vz;
+        const float tx = fminf(limx, fmaxf(-limx, txtz)) * vz;
+        const float ty = fminf(limy, fmaxf(-limy, tytz)) * vz;
+        M3 J = { { { vp.focal_x / vz, 0.0f, -(vp.focal_x * tx) / (vz * vz) },
+                   { 0.0f, vp.focal_y / vz, -(vp.focal_y * ty) / (vz * vz) },
+                   { 0, 0, 0 } } };
+        M3 Wm = { { { V[0], V[4], V[8] }, { V[1], V[5], V[9] }, { V[2], V[6], V[10] } } };
+        M3 T = m3_mul(Wm, J);
+        M3 Vrk = { { { c3[0], c3[1], c3[2] }, { c3[1], c3[3], c3[4] }, { c3[2], c3[4], c3[5] } } };
+        M3 cov = m3_mul(m3_mul(m3_t(T), m3_t(Vrk)), T);
+        const float ca = cov.c[0][0] + 0.3f, cb = cov.c[0][1], cc = cov.c[1][1] + 0.3f;
+
+        const float det = ca * cc - cb * cb;                   // forward.cu:219-223
+        if (det == 0.0f) break;
+        const float det_inv = 1.f / det;
+        const float con_a = cc * det_inv, con_b = -cb * det_inv, con_c = ca * det_inv;
+
+        const float mid = 0.5f * (ca + cc);                    // forward.cu:229-232
+        const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+        const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+        // ndc2Pix evaluates in double (auxiliary.h:41-44)
+        const float pix = (float)(((ndcx + 1.0) * vp.W - 1.0) * 0.5);
+        const float piy = (float)(((ndcy + 1.0) * vp.H - 1.0) * 0.5);
+        int minx, miny, maxx, maxy;
+        tile_rect(pix, piy, (int)my_radius, vp.gx, vp.gy, minx, miny, maxx, maxy);
+        const uint32_t area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
+        if (area == 0) break;
+
+        V3 rgb;
+        uint8_t cbits = 0;
+        if (colors_precomp != nullptr) {
+            rgb.x = colors_precomp[3 * (size_t)idx]; rgb.y = colors_precomp[3 * (size_t)idx + 1];
+            rgb.z = colors_precomp[3 * (size_t)idx + 2];
+        } else {
+            V3 dir = { px_w - vp.campos[0], py_w - vp.campos[1], pz_w - vp.campos[2] };
+            const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+            dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+            switch (vp.D) {
+                case 0: rgb = eval_sh<0>(shs, idx, vp.M, dir, cbits); break;
+                case 1: rgb = eval_sh<1>(shs, idx, vp.M, dir, cbits); break;
+                case 2: rgb = eval_sh<2>(shs, idx, vp.M, dir, cbits); break;
+                default: rgb = eval_sh<3>(shs, idx, vp.M, dir, cbits); break;
+            }
+        }
+        clamped[idx] = cbits;
+
+        GaussRec g;
+        g.x = pix; g.y = piy; g.ca = con_a; g.cb = con_b;
+        g.cc = con_c; g.opacity = opacities[idx]; g.r = rgb.x; g.g = rgb.y;
+        g.b = rgb.z; g.depth = vz; g.pad0 = 0.f; g.pad1 = 0.f;
+        float4* dst = reinterpret_cast<float4*>(rec + idx);
+        dst[0] = make_float4(g.x, g.y, g.ca, g.cb);
+        dst[1] = make_float4(g.cc, g.opacity, g.r, g.g);
+        dst[2] = make_float4(g.b, g.depth, 0.f, 0.f);
+
+        radius_out = (int)my_radius;
+        tiles_out = area;
+        key_out = __float_as_uint(vz);                         // vz > 0.2: bit order == float order
+    } while (false);
+
+    radii[idx] = radius_out;
+    tiles_touched[idx] = tiles_out;
+    depth_key[idx] = key_out;
+}
+
+__global__ void __launch_bounds__(256)
+k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict__ V, uint8_t* __restrict__ present)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float x = means3D[3 * (size_t)idx], y = means3D[3 * (size_t)idx + 1], z = means3D[3 * (size_t)idx + 2];
+    const float vz = V[2] * x + V[6] * y + V[10] * z + V[14];
+    present[idx] = (vz <= 0.2f) ? 0 : 1;                       // auxiliary.h:152-162 with prefiltered=false
+}
+
+}  // namespace
+
+void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
+                       const float* opacities, const float* shs, const float* cov3D_precomp,
+                       const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
+                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key, GeomHeader* hdr,
+                       uint32_t binning_capacity, hipStream_t s)
+{
+    if (vp.P <= 0) return;
+    dim3 grid((vp.P + 255) / 256), block(256);
+    hipLaunchKernelGGL(k_preprocess, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
+                       cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
+                       depth_key, hdr, binning_capacity);
+}
+
+void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
+                         hipStream_t s)
+{
+    (void)proj;   // the reference computes the clip-space point but tests only view-space z
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_mark_visible, dim3((P + 255) / 256), dim3(256), 0, s, P, means3D, view, present);
+}
+
+}  // namespace lr

@@ -1,0 +1,123 @@
+"""Python operator of the MI355X rasterizer: same public API as the reference's
+`depth_diff_gaussian_rasterization_min` package (RAST/depth_diff_gaussian_rasterization_min/__init__.py):
+
+    GaussianRasterizationSettings   12-field NamedTuple, same names and order   (:158-170)
+    GaussianRasterizer              nn.Module; forward(...) -> (color, radii, depth); markVisible (:172-221)
+    rasterize_gaussians             functional entry                                (:21-42)
+
+Error behaviour mirrored: plain `Exception` for bad SH/colour or scale/rotation/covariance
+combinations (:192-196); with settings.debug the inputs of a failing call are dumped to
+snapshot_fw.dump / snapshot_bw.dump before re-raising (:83-90, :133-140).
+"""
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+from . import config
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _snapshot(args, path):
+    torch.save(tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args), path)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """forward/backward wiring of RAST/.../__init__.py:44-156."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+                rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
+        capacity = config.capacity_for(means3D, rs)
+        try:
+            num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+                *args, binning_capacity=capacity)
+        except Exception:
+            if rs.debug:
+                _snapshot(args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+            raise
+        config.note_forward(means3D, rs, num_rendered, geom, capacity)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.binning_capacity = capacity
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
+        args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree,
+                rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+        try:
+            (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
+                *args, binning_capacity=ctx.binning_capacity)
+        except Exception:
+            if rs.debug:
+                _snapshot(args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+            raise
+        # order of the forward inputs (RAST/.../__init__.py:144-154); gradients of absent inputs are None-able
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of points in front of the near plane (view z > 0.2)."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None) == (colors_precomp is None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        scale_rot_given = scales is not None or rotations is not None
+        scale_rot_complete = scales is not None and rotations is not None
+        if (not scale_rot_complete and cov3D_precomp is None) or (scale_rot_given and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+        empty = torch.Tensor([])        # the reference's placeholder for an absent optional input
+        shs = empty if shs is None else shs
+        colors_precomp = empty if colors_precomp is None else colors_precomp
+        scales = empty if scales is None else scales
+        rotations = empty if rotations is None else rotations
+        cov3D_precomp = empty if cov3D_precomp is None else cov3D_precomp
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, rs)

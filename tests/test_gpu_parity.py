@@ -1,0 +1,208 @@
+"""GPU parity tests: the HIP rasterizer (public Python API -> C-ABI) against the CPU oracle on
+identical seeded inputs.  Tolerances are the ones stated in tests/helpers.py."""
+import numpy as np
+import pytest
+import torch
+
+from luciddreamer_amd import cameras, synthetic
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_forward_backward_small(hip_device, degree):
+    """C1-shaped case (10k Gaussians, 256x256) for every SH degree, forward + backward."""
+    cam, cloud = hp.box_setup(10_000, 256, 256)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    g = synthetic.upstream_grad(256, 256)
+    ref = hp.run_oracle(cloud, cam, degree, bg, g)
+    hip = hp.run_hip(cloud, cam, degree, bg, hip_device, g)
+    fig = hp.compare_forward(hip, ref)
+    gfig = hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+    print(fig, gfig)
+
+
+def test_sh_layout_M1(hip_device):
+    """sh of shape (P,1,3) with degree 0 ('pass sh (P,1,3) ... with degree 0')."""
+    cam, cloud = hp.box_setup(5_000, 200, 120, sh_coeffs=1)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(120, 200)
+    ref = hp.run_oracle(cloud, cam, 0, bg, g)
+    hip = hp.run_hip(cloud, cam, 0, bg, hip_device, g)
+    hp.compare_forward(hip, ref)
+    hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_ragged_image_and_big_splats(hip_device):
+    """Image size not a multiple of 16; large Gaussians exercise the wave-cooperative emission."""
+    cam, cloud = hp.box_setup(3_000, 250, 131, scale_mult=6.0)
+    bg = torch.tensor([1.0, 0.5, 0.0])
+    g = synthetic.upstream_grad(131, 250)
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+    hp.compare_forward(hip, ref)
+    hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_precomputed_colors_and_cov(hip_device):
+    """colors_precomp + cov3D_precomp input path (reference gaussian_renderer/__init__.py:62-63, 81-82)."""
+    from oracle import torch_oracle
+    cam, cloud = hp.box_setup(4_000, 160, 160)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(160, 160)
+    cov = torch_oracle.cov3d_from_scale_rot(cloud["scales"].double(), 1.0, cloud["rotations"].double()).float()
+    cols = torch.rand(4_000, 3, generator=torch.Generator().manual_seed(5))
+    ref = hp.run_oracle(cloud, cam, 0, bg, g, colors_precomp=cols, cov3D_precomp=cov)
+    hip = hp.run_hip(cloud, cam, 0, bg, hip_device, g, colors_precomp=cols, cov3D_precomp=cov)
+    hp.compare_forward(hip, ref)
+    hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "colors", "opacity", "means3D", "cov3D"])
+
+
+def test_scale_modifier(hip_device):
+    cam, cloud = hp.box_setup(4_000, 160, 96)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(96, 160)
+    ref = hp.run_oracle(cloud, cam, 2, bg, g, scale_modifier=1.7)
+    hip = hp.run_hip(cloud, cam, 2, bg, hip_device, g, scale_modifier=1.7)
+    hp.compare_forward(hip, ref)
+    hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_depth_ties_keep_index_order(hip_device):
+    """Exactly equal depths: the reference's stable sort keeps Gaussian-index order
+    (rasterizer_impl.cu:98-108, 304-309).  Duplicate every point so ties are everywhere."""
+    cam, cloud = hp.box_setup(1_500, 128, 128, scale_mult=2.0)
+    dup = {k: torch.cat([v, v], dim=0).contiguous() for k, v in cloud.items()}
+    # same position/depth, different colour -> the blend order is observable
+    dup["shs"][1_500:, 0, :] = -dup["shs"][1_500:, 0, :]
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(128, 128)
+    ref = hp.run_oracle(dup, cam, 0, bg, g)
+    hip = hp.run_hip(dup, cam, 0, bg, hip_device, g)
+    hp.compare_forward(hip, ref)
+    hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_camera_path_views(hip_device):
+    """Band cloud seen from rotate360 poses (pure rotations about the origin)."""
+    cloud = synthetic.make_cloud(20_000, "band", 3)
+    cams = cameras.rotate360_path(320, 180, n_views=5)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(180, 320)
+    for cam in cams[1:4]:
+        ref = hp.run_oracle(cloud, cam, 3, bg, g)
+        hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+        hp.compare_forward(hip, ref)
+        hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_empty_and_all_culled(hip_device):
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    cam = cameras.identity_camera(64, 48).to(hip_device)
+    tfx, tfy = hp.tan_fov(cam)
+    bg = torch.tensor([0.3, 0.6, 0.9], device=hip_device)
+    rs = GaussianRasterizationSettings(48, 64, tfx, tfy, bg, 1.0, cam.world_view_transform, cam.full_proj_transform,
+                                       0, cam.camera_center, False, False)
+    rast = GaussianRasterizer(rs)
+    # P == 0: zero images (rasterize_points.cu:68-82), not background
+    z3 = torch.zeros(0, 3, device=hip_device)
+    color, radii, depth = rast(means3D=z3, means2D=z3, opacities=torch.zeros(0, 1, device=hip_device),
+                               shs=torch.zeros(0, 16, 3, device=hip_device), scales=z3,
+                               rotations=torch.zeros(0, 4, device=hip_device))
+    assert color.shape == (3, 48, 64) and float(color.abs().max()) == 0.0 and radii.numel() == 0
+    # everything behind the camera: background everywhere, radii 0, zero gradients
+    cloud = synthetic.make_cloud(500, "box", 0)
+    cloud["means3D"][:, 2] = -cloud["means3D"][:, 2]
+    g = synthetic.upstream_grad(48, 64)
+    hip = hp.run_hip(cloud, cameras.identity_camera(64, 48), 0, bg.cpu(), hip_device, g)
+    assert (hip["radii"] == 0).all()
+    assert np.allclose(hip["color"], bg.cpu().numpy()[:, None, None])
+    assert float(np.abs(hip["depth"]).max()) == 0.0
+    for k, v in hip["grads"].items():
+        assert float(np.abs(v).max()) == 0.0, k
+
+
+def test_single_gaussian_analytic(hip_device):
+    """Isotropic Gaussian on the optical axis: peak colour = min(0.99, o) * rgb, radius = ceil(3*sqrt(s_px^2+0.3))
+    (SURVEY 8c analytic case)."""
+    W = H = 64
+    cam = cameras.identity_camera(W, H)
+    s, z, o = 0.05, 4.0, 0.8
+    cloud = dict(means3D=torch.tensor([[0.0, 0.0, z]]), scales=torch.full((1, 3), s),
+                 rotations=torch.tensor([[1.0, 0, 0, 0]]), opacities=torch.tensor([[o]]),
+                 shs=torch.zeros(1, 16, 3))
+    rgb = torch.tensor([[0.2, 0.5, 0.9]])
+    hip = hp.run_hip(cloud, cam, 0, torch.zeros(3), hip_device, colors_precomp=rgb)
+    focal = cameras.fov2focal(cam.FoVx, W)
+    s_px2 = (s * focal / z) ** 2
+    assert hip["radii"][0] == int(np.ceil(3.0 * np.sqrt(s_px2 + 0.3)))
+    # the mean projects to pixel coordinate (W-1)/2 = 31.5: the 4 central pixels are 0.5 px away on each axis
+    d2 = 0.5
+    expect = o * np.exp(-0.5 * d2 / (s_px2 + 0.3)) * rgb.numpy()[0]
+    assert np.allclose(hip["color"][:, 31, 31], expect, atol=2e-6)
+    assert abs(hip["depth"][0, 31, 31] - z) < 1e-5
+
+
+def test_prefiltered_trap_is_an_error(hip_device):
+    """prefiltered=True with a culled point is a hard error (auxiliary.h:156-160)."""
+    cam, cloud = hp.box_setup(200, 64, 64)
+    cloud["means3D"][0, 2] = -1.0
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        hp.run_hip(cloud, cam, 0, torch.zeros(3), hip_device, prefiltered=True)
+
+
+def test_depth_gradient_is_ignored(hip_device):
+    """A loss on depth yields zero parameter gradient in the reference (backward.cu:457-464, 539-554)."""
+    cam, cloud = hp.box_setup(2_000, 96, 96)
+    gz = torch.zeros(3, 96, 96)
+    gd = torch.randn(1, 96, 96, generator=torch.Generator().manual_seed(2))
+    hip = hp.run_hip(cloud, cam, 1, torch.zeros(3), hip_device, gz, grad_depth=gd)
+    for k, v in hip["grads"].items():
+        assert float(np.abs(v).max()) == 0.0, k
+
+
+def test_mark_visible(hip_device):
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from oracle import oracle
+    cloud = synthetic.make_cloud(10_000, "band", 1)
+    cam = cameras.rotate360_path(64, 64, n_views=4)[1]
+    camd = cam.to(hip_device)
+    tfx, tfy = hp.tan_fov(cam)
+    rs = GaussianRasterizationSettings(64, 64, tfx, tfy, torch.zeros(3, device=hip_device), 1.0,
+                                       camd.world_view_transform, camd.full_proj_transform, 0, camd.camera_center,
+                                       False, False)
+    vis = GaussianRasterizer(rs).markVisible(cloud["means3D"].to(hip_device)).cpu().numpy()
+    ref = oracle.mark_visible(cloud["means3D"].numpy(), cam.world_view_transform.numpy(), cam.full_proj_transform.numpy())
+    assert vis.dtype == np.bool_ and np.array_equal(vis, ref)
+
+
+def test_async_mode_matches_exact(hip_device):
+    """Async (no host sync) forward/backward gives the same result as exact mode; overflow is reported."""
+    from luciddreamer_amd import _C, config
+    cam, cloud = hp.box_setup(8_000, 192, 128)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(128, 192)
+    exact = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+    config.reset()
+    config.set_async(True, headroom=1.5)
+    try:
+        first = hp.run_hip(cloud, cam, 3, bg, hip_device, g)      # measures exactly
+        second = hp.run_hip(cloud, cam, 3, bg, hip_device, g)     # async, capacity from the high-water mark
+        config.drain()
+    finally:
+        config.set_async(False)
+        config.reset()
+    for run in (first, second):
+        assert np.array_equal(run["color"], exact["color"]) and np.array_equal(run["radii"], exact["radii"])
+        assert np.array_equal(run["depth"], exact["depth"])
+    # too small a capacity: flagged, never out of bounds
+    dev = hip_device
+    tfx, tfy = hp.tan_fov(cam)
+    camd = cam.to(dev)
+    out = _C.rasterize_gaussians(bg.to(dev), cloud["means3D"].to(dev), torch.Tensor([]), cloud["opacities"].to(dev),
+                                 cloud["scales"].to(dev), cloud["rotations"].to(dev), 1.0, torch.Tensor([]),
+                                 camd.world_view_transform, camd.full_proj_transform, tfx, tfy, 128, 192,
+                                 cloud["shs"].to(dev), 3, camd.camera_center, False, False, binning_capacity=100)
+    with pytest.raises(RuntimeError, match="capacity"):
+        _C.check(out[4])
