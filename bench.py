@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""bench.py -- views/s forward+backward of the MI355X Gaussian-splat rasterizer (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2] [--views V]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch of synthetic views: every rank renders its V
+views of the camera path forward+backward (rasterizer autograd op, upstream gradient dL/dcolor =
+N(0,1)), gradients accumulate in one flat fp32 bucket, and (N > 1) the bucket is all-reduced once
+over RCCL.  Weak scaling: V views per rank per step, N*V distinct views per step.
+Inputs are resident in HBM before the timed region; data is synthetic.
+
+Workloads (BASELINE.json configs):
+  c3 (default; the metric's configuration): 1e6 Gaussians, SH degree 3, 1920x1080, band cloud,
+      rotate360 camera path, V = 30 views per rank per step.
+  c2: 1e5 Gaussians, SH degree 3, 1920x1080, box cloud, single identity view repeated V times.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library
+on the launch stream) and `cpu_baseline` (the CPU oracle = "port" of the reference semantics, timed
+on this box's host cores on one view of the same workload).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+NCOEF = {0: 1, 1: 4, 2: 9, 3: 16}
+
+
+def stage_bytes(stage, P, V, R, N, T, K, M):
+    """Algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 3, one read + one write per stage)."""
+    if stage == "preprocess":
+        return 12 * P + V * (32 + 12 * K) + 8 * P + 40 * V
+    if stage == "render_fwd":
+        return 44 * R + 24 * N
+    if stage == "render_bwd":
+        return 40 * R + 20 * N + 44 * V
+    if stage == "gauss_bwd":
+        return P * (108 + 12 * M) + 92 * V + V * (135 + 24 * K)
+    return None
+
+
+def path_bytes(P, V, R, N, T, K, M):
+    b_f = (12 * P + V * (32 + 12 * K)) + (8 * P + 40 * V) + 8 * P + (20 * V + 12 * R) + 24 * R + (8 * R + 8 * T) + (44 * R + 24 * N)
+    b_b = (40 * R + 20 * N + 44 * V) + P * (108 + 12 * M) + 92 * V + V * (135 + 24 * K)
+    return b_f, b_b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2"])
+    ap.add_argument("--views", type=int, default=None, help="views per rank per step")
+    ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
+    ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from luciddreamer_amd import _C, _lib, cameras, config, parallel, synthetic
+    from luciddreamer_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    rank, world, dev = parallel.init_distributed()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    W, H, degree = 1920, 1080, 3
+    if args.workload == "c3":
+        P = args.gaussians or 1_000_000
+        V = args.views or 30
+        cloud = synthetic.make_cloud(P, "band", 0)
+        path = cameras.rotate360_path(W, H, n_views=V * world)
+        my_cams = [path[i] for i in parallel.shard_views(len(path), rank, world)]
+        wl_name = f"C3: {P} Gaussians, SH degree 3, 1920x1080, band cloud, rotate360 path, {V} views/rank/step"
+    else:
+        P = args.gaussians or 100_000
+        V = args.views or 30
+        cloud = synthetic.make_cloud(P, "box", 0)
+        my_cams = [cameras.identity_camera(W, H)] * V
+        wl_name = f"C2: {P} Gaussians, SH degree 3, 1920x1080, box cloud, identity view x{V}/rank/step"
+    M = cloud["shs"].shape[1]
+    K = NCOEF[degree]
+    N = W * H
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    leaf = {k: v.to(dev).requires_grad_(True) for k, v in cloud.items()}
+    params = [leaf["means3D"], leaf["scales"], leaf["rotations"], leaf["opacities"], leaf["shs"]]
+    grads = parallel.FlatGrads(params)
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    grad_color = synthetic.upstream_grad(H, W).to(dev)
+    bg = torch.zeros(3, device=dev)
+    cams = [c.to(dev) for c in my_cams]
+    rasterizers = []
+    for c in cams:
+        rs = GaussianRasterizationSettings(H, W, math.tan(c.FoVx * 0.5), math.tan(c.FoVy * 0.5), bg, 1.0,
+                                           c.world_view_transform, c.full_proj_transform, degree, c.camera_center,
+                                           False, False)
+        rasterizers.append(GaussianRasterizer(rs))
+
+    # per-view R (= num_rendered) and V (= visible count), measured once in exact mode; also seeds the
+    # async-mode binning capacity so no view in the timed region needs a host round trip
+    empty = torch.Tensor([])
+    view_stats = []
+    seen = {}
+    with torch.no_grad():
+        for c, r in zip(cams, rasterizers):
+            key = id(c.world_view_transform)
+            if key not in seen:
+                rs = r.raster_settings
+                out = _C.rasterize_gaussians(bg, leaf["means3D"], empty, leaf["opacities"], leaf["scales"],
+                                             leaf["rotations"], 1.0, empty, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+                                             rs.tanfovy, H, W, leaf["shs"], degree, rs.campos, False, False)
+                seen[key] = (int(out[0]), int((out[3] > 0).sum().item()))
+            view_stats.append(seen[key])
+    R_mean = sum(s[0] for s in view_stats) / len(view_stats)
+    V_mean = sum(s[1] for s in view_stats) / len(view_stats)
+    config.reset()
+    if not args.exact:
+        config.set_async(True, headroom=1.25)
+        config._hwm[(dev.index, P, H, W)] = max(s[0] for s in view_stats)
+
+    def step():
+        grads.zero_()
+        means2D.grad = None
+        for r in rasterizers:
+            color, radii, depth = r(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
+                                    shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+            color.backward(grad_color)
+        grads.all_reduce()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def timed(n_steps):
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    for _ in range(args.warmup):
+        step()
+    dt = timed(args.steps)
+    config.drain()
+    views_total = world * V * args.steps
+    value = views_total / dt
+    ms_per_step = dt / args.steps * 1e3
+
+    # ---- roofline leg: same steps again with per-stage HIP events recorded on the launch stream ----
+    _lib.profile_enable(True)
+    dt_prof = timed(args.steps)
+    stages = _lib.profile_read()
+    _lib.profile_enable(False)
+    config.drain()
+    single_kernel = ("preprocess", "render_fwd", "render_bwd", "gauss_bwd")
+    dom = max(single_kernel, key=lambda s: stages[s][0])
+    dom_ms, dom_calls = stages[dom]
+    dom_avg_s = dom_ms / max(dom_calls, 1) * 1e-3
+    dom_bytes = stage_bytes(dom, P, V_mean, R_mean, N, T, K, M)
+    achieved = dom_bytes / dom_avg_s / 1e9
+    b_f, b_b = path_bytes(P, V_mean, R_mean, N, T, K, M)
+    per_rank_views_s = value / world
+    roofline = {
+        "bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
+        "launches": dom_calls,
+        "path_bytes_per_view": int(b_f + b_b),
+        "path_frac_of_hbm_peak": round((b_f + b_b) * per_rank_views_s / (HBM_PEAK_GBS * 1e9), 5),
+        "stage_ms_per_view": {k: round(v[0] / max(V * args.steps, 1), 4) for k, v in stages.items()},
+        "instrumented_views_per_s": round(world * V * args.steps / dt_prof, 2),
+    }
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_baseline = run_cpu_baseline(cloud, my_cams[len(my_cams) // 2], degree, H, W)
+
+    if rank == 0:
+        line = {
+            "metric": "views/sec fwd+bwd @1080p (1e6 Gaussians)" if args.workload == "c3" else "views/sec fwd+bwd @1080p (1e5 Gaussians)",
+            "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl_name, "views_per_rank_per_step": V, "gaussians": P, "visible_mean": round(V_mean, 1),
+                       "num_rendered_mean": round(R_mean, 1), "sh_degree": degree, "resolution": [W, H],
+                       "mode": "exact (host sync per view)" if args.exact else "async (no host sync per view)",
+                       "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)",
+                       "grad_bucket_bytes": int(grads.flat.numel() * 4)},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run_cpu_baseline(cloud, cam, degree, H, W):
+    """Time the CPU oracle (the 'port' of the reference semantics; the reference has no CPU path and its
+    CUDA sources cannot be built here) on ONE view fwd+bwd of the same workload, all host cores (OpenMP)."""
+    import numpy as np
+    from luciddreamer_amd import synthetic
+    from oracle import oracle
+    n = lambda t: t.detach().cpu().numpy()
+    g = n(synthetic.upstream_grad(H, W))
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    oracle.lib()
+    t0 = time.perf_counter()
+    res = oracle.forward(np.zeros(3, np.float32), n(cloud["means3D"]), None, n(cloud["opacities"]), n(cloud["scales"]),
+                         n(cloud["rotations"]), 1.0, None, n(cam.world_view_transform), n(cam.full_proj_transform),
+                         tfx, tfy, H, W, n(cloud["shs"]), degree, n(cam.camera_center))
+    t1 = time.perf_counter()
+    oracle.backward(res, g)
+    t2 = time.perf_counter()
+    cores = os.cpu_count() or 1
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": round(1.0 / (t2 - t0), 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"1 view fwd+bwd of the same workload ({t1 - t0:.2f}s fwd + {t2 - t1:.2f}s bwd), OpenMP over {cores} host threads",
+            "cpu_model": model}
+
+
+if __name__ == "__main__":
+    main()

@@ -151,6 +151,15 @@ int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  * num_rendered via *num_rendered (may be NULL); returns 0, LR_ERR_OVERFLOW or LR_ERR_PREFILTERED. */
 int lr_check(const char* geom_buffer, long long* num_rendered, void* stream);
 
+/* Optional per-stage timing with HIP events recorded on the call's stream (bench.py roofline leg).
+ * lr_profile_enable(1) clears and starts recording, (0) stops; returns the number of stages.
+ * lr_profile_read waits for the recorded events and returns, per stage, the summed elapsed
+ * milliseconds and the number of recorded calls.  Stage names: lr_profile_stage_name(i).
+ * The stages "preprocess", "render_fwd", "render_bwd", "gauss_bwd" are exactly one kernel launch each. */
+int lr_profile_enable(int on);
+const char* lr_profile_stage_name(int stage);
+int lr_profile_read(double* ms_per_stage, long long* calls_per_stage, int n_stages);
+
 /* Mean squared distance to the 3 nearest other points (simple-knn distCUDA2).
  * points [P,3] -> out [P].  workspace: lr_dist2_workspace_bytes(P) device bytes. */
 size_t lr_dist2_workspace_bytes(int P);

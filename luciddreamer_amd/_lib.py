@@ -24,7 +24,8 @@ _lib = None
 _lock = threading.Lock()
 
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
-           "lr_backward", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2")
+           "lr_backward", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
+           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read")
 
 
 def lib():
@@ -72,8 +73,31 @@ def lib():
         L.lr_dist2_workspace_bytes.argtypes = [ci]
         L.lr_dist2.restype = ci
         L.lr_dist2.argtypes = [ci, vp, vp, vp, vp]
+        L.lr_profile_enable.restype = ci
+        L.lr_profile_enable.argtypes = [ci]
+        L.lr_profile_stage_name.restype = ctypes.c_char_p
+        L.lr_profile_stage_name.argtypes = [ci]
+        L.lr_profile_read.restype = ci
+        L.lr_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ll), ci]
         _lib = L
     return _lib
+
+
+def profile_enable(on=True):
+    """Start (clearing previous records) or stop per-stage HIP-event timing inside the library."""
+    return lib().lr_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{stage: (total_ms, calls)} for everything recorded since profile_enable(True); waits for the events."""
+    L = lib()
+    n = 16                                   # >= number of stages (lr_profile_read returns the real count)
+    ms = (ctypes.c_double * n)()
+    calls = (ctypes.c_longlong * n)()
+    cnt = L.lr_profile_read(ms, calls, n)
+    if cnt < 0:
+        raise RuntimeError(last_error())
+    return {L.lr_profile_stage_name(i).decode(): (ms[i], int(calls[i])) for i in range(cnt)}
 
 
 def last_error():

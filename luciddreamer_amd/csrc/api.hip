@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -37,6 +38,35 @@ int fail(int code, const std::string& msg)
                 return fail(LR_ERR_HIP, std::string("[HIP ERROR] after ") + what + ": " + hipGetErrorString(e__)); \
         }                                                                                         \
     } while (0)
+
+// ---- optional per-stage HIP-event timing (used by bench.py for the roofline figures) ----------
+enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_RENDER_FWD,
+             ST_GRAD_ZERO, ST_RENDER_BWD, ST_GAUSS_BWD, ST_COUNT };
+const char* const kStageNames[ST_COUNT] = { "preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges",
+                                            "render_fwd", "grad_zero", "render_bwd", "gauss_bwd" };
+struct ProfRec { int stage; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+
+hipEvent_t prof_event()
+{
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+struct ProfScope {
+    hipStream_t s; ProfRec r; bool on;
+    ProfScope(int stage, hipStream_t s_) : s(s_), on(g_prof_on)
+    {
+        if (on) { r.stage = stage; r.e0 = prof_event(); r.e1 = prof_event(); (void)hipEventRecord(r.e0, s); }
+    }
+    ~ProfScope()
+    {
+        if (on) { (void)hipEventRecord(r.e1, s); g_prof_recs.push_back(r); }
+    }
+};
 
 int bits_for(uint32_t max_value)
 {
@@ -124,20 +154,23 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
 
     if (P > 0) {
         // K1: cull / project / conic / colour -> GaussRec, radii, tile counts, depth keys
+        { ProfScope ps(ST_PREPROCESS, s);
         launch_preprocess(vp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
                           prefiltered != 0, radii, rec, clamped, tiles_touched, gkey_a, hdr,
-                          (uint32_t)binning_capacity, s);
+                          (uint32_t)binning_capacity, s); }
         LR_DEBUG_SYNC(debug, s, "preprocess");
 
         // depth order of the Gaussians (stable, value = index); culled ones (key 0xFFFFFFFF) go last
         uint32_t *sorted_depth_keys, *order;
+        { ProfScope ps(ST_DEPTH_SORT, s);
         radix_sort_pairs(gkey_a, gkey_b, gval_a, gval_b, /*iota*/ true, &hdr->P, P, 32, ghist, &sorted_depth_keys,
-                         &order, s);
+                         &order, s); }
         (void)sorted_depth_keys;
         LR_DEBUG_SYNC(debug, s, "depth sort");
 
         // exclusive scan of tile counts in depth order; total -> header
-        launch_scan_tiles(P, order, tiles_touched, offsets, scan_sums, hdr, s);
+        { ProfScope ps(ST_SCAN, s);
+        launch_scan_tiles(P, order, tiles_touched, offsets, scan_sums, hdr, s); }
         LR_DEBUG_SYNC(debug, s, "scan");
 
         if (binning_capacity == 0) {
@@ -162,18 +195,21 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
         uint32_t* bhist = reinterpret_cast<uint32_t*>(bin + BL.hist);
 
         if (R_bound > 0) {
-            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, bkey_a, bval_a, s);
+            { ProfScope ps(ST_EMIT, s);
+            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, bkey_a, bval_a, s); }
             LR_DEBUG_SYNC(debug, s, "emit");
             // stable partition by tile id: with the depth order of emission this is the reference's
             // (tile | depth) order (rasterizer_impl.cu:301-309)
+            { ProfScope ps(ST_TILE_SORT, s);
             radix_sort_pairs(bkey_a, bkey_b, bval_a, bval_b, /*iota*/ false, &hdr->num_sorted, R_bound, tile_bits,
-                             bhist, &inst_keys_sorted, &point_list, s);
+                             bhist, &inst_keys_sorted, &point_list, s); }
             LR_DEBUG_SYNC(debug, s, "tile sort");
         } else {
             inst_keys_sorted = (tile_passes & 1) ? bkey_b : bkey_a;
             point_list = (tile_passes & 1) ? bval_b : bval_a;
         }
-        launch_ranges(inst_keys_sorted, hdr, R_bound, num_tiles, ranges, s);
+        { ProfScope ps(ST_RANGES, s);
+        launch_ranges(inst_keys_sorted, hdr, R_bound, num_tiles, ranges, s); }
         LR_DEBUG_SYNC(debug, s, "ranges");
     } else {
         (void)binning_alloc(bin_layout(0).total, binning_user);
@@ -181,8 +217,9 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     }
 
     // K6: blend
+    { ProfScope ps(ST_RENDER_FWD, s);
     launch_render_fwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, out_color,
-                      out_depth, s);
+                      out_depth, s); }
     LR_DEBUG_SYNC(debug, s, "render");
     LR_HIP_CHECK(hipGetLastError());
 
@@ -241,12 +278,15 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     vp.scale_modifier = scale_modifier;
     vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
 
-    LR_HIP_CHECK(hipMemsetAsync(grad, 0, (size_t)P * sizeof(GradRec), s));
-    launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix, grad, s);
+    { ProfScope ps(ST_GRAD_ZERO, s);
+    LR_HIP_CHECK(hipMemsetAsync(grad, 0, (size_t)P * sizeof(GradRec), s)); }
+    { ProfScope ps(ST_RENDER_BWD, s);
+    launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix, grad, s); }
     LR_DEBUG_SYNC(debug, s, "render backward");
+    { ProfScope ps(ST_GAUSS_BWD, s);
     launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, grad,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                     dL_drot, s);
+                     dL_drot, s); }
     LR_DEBUG_SYNC(debug, s, "preprocess backward");
     LR_HIP_CHECK(hipGetLastError());
     return 0;
@@ -275,6 +315,30 @@ int lr_check(const char* geom_buffer, long long* num_rendered, void* stream_)
     if (meta[2]) return fail(LR_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     if (meta[1]) return fail(LR_ERR_OVERFLOW, "binning capacity exceeded");
     return 0;
+}
+
+int lr_profile_enable(int on)
+{
+    for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+    g_prof_recs.clear();
+    g_prof_on = on != 0;
+    return ST_COUNT;
+}
+
+const char* lr_profile_stage_name(int stage) { return (stage >= 0 && stage < ST_COUNT) ? kStageNames[stage] : ""; }
+
+int lr_profile_read(double* ms_per_stage, long long* calls_per_stage, int n_stages)
+{
+    if (!ms_per_stage || !calls_per_stage || n_stages < ST_COUNT) return fail(LR_ERR_INVALID_ARG, "need ST_COUNT slots");
+    for (int i = 0; i < n_stages; i++) { ms_per_stage[i] = 0.0; calls_per_stage[i] = 0; }
+    for (auto& r : g_prof_recs) {
+        LR_HIP_CHECK(hipEventSynchronize(r.e1));
+        float ms = 0.f;
+        LR_HIP_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        ms_per_stage[r.stage] += ms;
+        calls_per_stage[r.stage] += 1;
+    }
+    return ST_COUNT;
 }
 
 size_t lr_dist2_workspace_bytes(int P) { return lr::dist2_workspace_bytes(P); }

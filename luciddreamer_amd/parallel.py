@@ -1,0 +1,123 @@
+"""View-level data parallelism for the rasterizer: one process per GPU, views of a camera path
+sharded across ranks, ONE flat fp32 gradient all-reduce per optimisation step (RCCL over xGMI via
+torch.distributed backend "nccl"; "gloo" on CPU for tests).
+
+The reference has no distributed code on this path; its training loop renders
+one view per iteration (/root/reference/luciddreamer.py:291-304).  Views are independent given the
+(replicated) Gaussian parameters and their gradients add, so the path shards with a single exchange:
+
+    rank r renders views r, r+n, r+2n, ... of the step and accumulates parameter gradients locally
+    into a FlatGrads bucket (the .grad of every parameter is a view into one contiguous buffer, so
+    autograd accumulates in place and nothing is packed or copied for the collective);
+    all_reduce(SUM) of the bucket -- 59 floats = 236 B per Gaussian (xyz 3, f_dc 3, f_rest 45,
+    opacity 1, scaling 3, rotation 4; /root/reference/scene/gaussian_model.py:143-148);
+    identical optimiser steps on every rank keep the replicas bit-identical.
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): one large message per step lets RCCL use all
+links; many small per-tensor all-reduces would be latency- and per-link-bound.  Densification
+statistics consumed by the unchanged GaussianModel are reduced as well: xyz_gradient_accum and denom
+(SUM) and max_radii2D (MAX) (scene/gaussian_model.py:405-407, luciddreamer.py:310-311).
+"""
+import os
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: Optional[str] = None, device: Optional[torch.device] = None):
+    """Initialise torch.distributed from the torchrun environment (RANK, LOCAL_RANK, WORLD_SIZE,
+    MASTER_ADDR, MASTER_PORT).  Returns (rank, world_size, device).  No-op for WORLD_SIZE == 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if device is None:
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
+            device = torch.device("cuda", local % torch.cuda.device_count())
+        else:
+            device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if device.type == "cuda" else "gloo"   # "nccl" IS RCCL on ROCm
+        kwargs = {}
+        if backend == "nccl":
+            kwargs["device_id"] = device
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, device
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def shard_views(n_views: int, rank: Optional[int] = None, world: Optional[int] = None) -> List[int]:
+    """Indices of the views rank `rank` renders: rank-strided (view i -> rank i mod n)."""
+    rank = get_rank() if rank is None else rank
+    world = world_size() if world is None else world
+    return list(range(rank, n_views, world))
+
+
+class FlatGrads:
+    """One contiguous fp32 buffer holding the gradients of all parameters; p.grad are views into it."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        self.params = list(params)
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        self.views = []
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            p.grad = v
+            self.views.append(v)
+            off += p.numel()
+
+    def zero_(self):
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):   # re-attach in case an optimiser set grads to None
+            p.grad = v
+
+    def all_reduce(self, average: bool = False, async_op: bool = False):
+        if world_size() == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        if average and not async_op:
+            self.flat.div_(world_size())
+        return work
+
+
+def all_reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor,
+                                   max_radii2D: torch.Tensor):
+    """SUM, SUM, MAX across ranks (in place)."""
+    if world_size() == 1:
+        return
+    dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM)
+    dist.all_reduce(denom, op=dist.ReduceOp.SUM)
+    dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
+
+
+def dp_step(views: Sequence, params: Sequence[torch.Tensor], loss_fn: Callable, grads: Optional[FlatGrads] = None,
+            rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True) -> FlatGrads:
+    """One data-parallel gradient step over `views`.
+
+    loss_fn(view, view_index) -> scalar loss of that view (it renders through the rasterizer).
+    Every rank calls this with the SAME `views` list; rank r processes views r, r+n, ...; after the
+    single all-reduce every rank holds sum_over_all_views dLoss/dparams in grads.flat.
+    """
+    if grads is None:
+        grads = FlatGrads(params)
+    grads.zero_()
+    for i in shard_views(len(views), rank, world):
+        loss = loss_fn(views[i], i)
+        loss.backward()
+    if reduce:
+        grads.all_reduce()
+    return grads
