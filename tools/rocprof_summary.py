@@ -22,7 +22,7 @@ def main():
             short = name.replace("lr::(anonymous namespace)::", "lr::")
             if len(short) > 90:
                 short = short[:87] + "..."
-            f.write(f"| `{short}` | {calls} | {total / 1000.0:.1f} | {avg / 1000.0:.3f} | {pct:.2f} |\n")
+            f.write(f"| `{short}` | {calls} | {total:.1f} | {avg:.3f} | {pct:.2f} |\n")
     print(out_path)
 
 
