@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
     ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-accumulate", action="store_true",
+                    help="let autograd accumulate dense per-view gradients instead of the in-kernel accumulation")
     args = ap.parse_args()
 
     from luciddreamer_amd import _C, _lib, cameras, config, parallel, synthetic
@@ -128,13 +130,16 @@ def main():
     R_mean = sum(s[0] for s in view_stats) / len(view_stats)
     V_mean = sum(s[1] for s in view_stats) / len(view_stats)
     config.reset()
+    config.set_fused_grad_accumulation(not args.no_fused_accumulate)
     if not args.exact:
         config.set_async(True, headroom=1.25)
         config._hwm[(dev.index, P, H, W)] = max(s[0] for s in view_stats)
 
+    m2d_grad = torch.zeros(P, 3, device=dev)
+
     def step():
         grads.zero_()
-        means2D.grad = None
+        means2D.grad = m2d_grad.zero_() if not args.no_fused_accumulate else None
         for r in rasterizers:
             color, radii, depth = r(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
                                     shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])

@@ -49,6 +49,17 @@ typedef char* (*lr_alloc_fn)(size_t bytes, void* user);
 #define LR_ERR_ALLOC         (-14)  /* allocator callback returned NULL */
 #define LR_NUM_RENDERED_ON_DEVICE (-1) /* lr_forward return value in async mode */
 
+/* lr_backward accumulate_mask bits (one per gradient output, in argument order) */
+#define LR_ACC_MEAN2D  (1u << 0)
+#define LR_ACC_CONIC   (1u << 1)
+#define LR_ACC_OPACITY (1u << 2)
+#define LR_ACC_COLOR   (1u << 3)
+#define LR_ACC_MEAN3D  (1u << 4)
+#define LR_ACC_COV3D   (1u << 5)
+#define LR_ACC_SH      (1u << 6)
+#define LR_ACC_SCALE   (1u << 7)
+#define LR_ACC_ROT     (1u << 8)
+
 const char* lr_last_error(void);
 const char* lr_version(void);
 
@@ -104,7 +115,10 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
  * (exact mode: R >= 0, capacity 0; async mode: R = LR_NUM_RENDERED_ON_DEVICE, capacity > 0; no host
  * synchronisation happens in either mode -- use lr_check to learn about an overflow).  dL_depths is accepted and ignored, exactly as the reference does
  * (RAST/cuda_rasterizer/backward.cu:457-464, 539-554 are commented out).
- * Outputs (all fully written, rows of culled Gaussians are zero):
+ * accumulate_mask: bit k set (LR_ACC_*) => that output is ACCUMULATED into (rows of visible Gaussians are
+ * added to the existing contents, rows of culled Gaussians are not touched); bit clear => the output is
+ * fully written (zero rows for culled Gaussians), no pre-fill needed.  0 reproduces the reference contract.
+ * Outputs:
  *   dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (slots x,y,w; may be NULL), dL_dopacity [P],
  *   dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL iff shs NULL),
  *   dL_dscale [P,3], dL_drot [P,4] (written as zeros when cov3D_precomp is used).
@@ -141,6 +155,7 @@ int lr_backward(int P, int D, int M, int R,
                 float* dL_drot,
                 int debug,
                 long long binning_capacity,
+                unsigned int accumulate_mask,
                 void* stream);
 
 /* present[P] (1 byte each) = view-space z > 0.2.  Returns 0 or a negative LR_ERR_*. */

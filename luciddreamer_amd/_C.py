@@ -19,6 +19,8 @@ from . import _lib
 
 NUM_CHANNELS = 3
 _tls = threading.local()
+# lr_backward accumulate_mask bit per gradient output (LR_ACC_* in include/lucid_raster.h)
+ACC_BITS = {"means2D": 0, "opacity": 2, "colors": 3, "means3D": 4, "cov3D": 5, "sh": 6, "scales": 7, "rotations": 8}
 
 
 def _alloc_cb(nbytes, user):
@@ -113,7 +115,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 debug, *, binning_capacity=0):
+                                 debug, *, binning_capacity=0, accumulate_into=None):
+    """accumulate_into (optional): {name: tensor} with names among ACC_BITS; the gradient of that input is
+    ADDED in place into the given contiguous float32 tensor (rows of culled Gaussians untouched) and the
+    corresponding slot of the returned tuple is None."""
     _require_device(means3D, "means3D")
     dev = means3D.device
     L = _lib.lib()
@@ -121,16 +126,27 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0 and sh.size(0) != 0) else 0
 
-    # All nine are fully written by the library (culled rows = 0): no zero-fill (cf. rasterize_points.cu:154-162).
+    # Outputs are fully written by the library (culled rows = 0): no zero-fill (cf. rasterize_points.cu:154-162).
     opt = dict(dtype=torch.float32, device=dev)
-    dL_dmeans3D = torch.empty((P, 3), **opt)
-    dL_dmeans2D = torch.empty((P, 3), **opt)
-    dL_dcolors = torch.empty((P, NUM_CHANNELS), **opt)
-    dL_dopacity = torch.empty((P, 1), **opt)
-    dL_dcov3D = torch.empty((P, 6), **opt)
-    dL_dsh = torch.empty((P, M, 3), **opt)
-    dL_dscales = torch.empty((P, 3), **opt)
-    dL_drotations = torch.empty((P, 4), **opt)
+    acc = accumulate_into or {}
+    mask = 0
+    shapes = {"means3D": (P, 3), "means2D": (P, 3), "colors": (P, NUM_CHANNELS), "opacity": (P, 1), "cov3D": (P, 6),
+              "sh": (P, M, 3), "scales": (P, 3), "rotations": (P, 4)}
+    outs = {}
+    for name, shape in shapes.items():
+        t = acc.get(name)
+        if t is not None:
+            n = 1
+            for d in shape:
+                n *= d
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or t.numel() != n:
+                raise RuntimeError(f"accumulate_into[{name!r}] must be a contiguous float32 tensor of {n} elements on {dev}")
+            mask |= 1 << ACC_BITS[name]
+            outs[name] = t
+        else:
+            outs[name] = torch.empty(shape, **opt)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_dopacity = outs["means3D"], outs["means2D"], outs["colors"], outs["opacity"]
+    dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = outs["cov3D"], outs["sh"], outs["scales"], outs["rotations"]
     if P != 0:
         means3D_c = _f32(means3D, dev, "means3D")
         bg = _f32(background, dev, "background")
@@ -154,10 +170,11 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
                                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh) if M else None,
                                dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
-                               int(binning_capacity), _stream(dev))
+                               int(binning_capacity), mask, _stream(dev))
         if rc < 0:
             _lib.raise_for(rc, "rasterize_gaussians_backward")
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    r = lambda name: None if name in acc and acc[name] is not None else outs[name]
+    return (r("means2D"), r("colors"), r("opacity"), r("means3D"), r("cov3D"), r("sh"), r("scales"), r("rotations"))
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

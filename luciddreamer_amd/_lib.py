@@ -64,7 +64,7 @@ def lib():
                                   vp, vp, vp, cf, cf, vp,                        # view proj campos tanx tany radii
                                   vp, vp, vp, vp, vp,                            # geom binning img dL_dpix dL_ddepth
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp,            # 9 gradient outputs
-                                  ci, ll, vp]                                    # debug capacity stream
+                                  ci, ll, ctypes.c_uint, vp]                     # debug capacity accumulate_mask stream
         L.lr_mark_visible.restype = ci
         L.lr_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
         L.lr_check.restype = ci

@@ -13,6 +13,7 @@ accept a deferred error keep exact mode.
 import torch
 
 _async = False
+_fused_accumulate = False
 _headroom = 1.3
 _hwm = {}            # (device, P, H, W) -> largest num_rendered observed
 _pending = []        # [(event, pinned_header, key)]
@@ -25,6 +26,21 @@ def set_async(enabled: bool, headroom: float = 1.3):
     _headroom = float(headroom)
     if not enabled:
         drain()
+
+
+def set_fused_grad_accumulation(enabled: bool):
+    """When on, the backward of the rasterizer op adds the gradient of every LEAF input whose .grad tensor
+    already exists (contiguous float32) directly into that .grad inside the HIP kernel -- touching only the
+    rows of visible Gaussians -- and returns None for it, instead of materialising a dense gradient that
+    autograd then adds in a separate pass.  Numerically this is autograd's own `grad += new` (same sum per
+    element); tensor hooks registered on those leaves are NOT run, hence opt-in.  Used by the data-parallel
+    multi-view step (luciddreamer_amd.parallel / bench.py)."""
+    global _fused_accumulate
+    _fused_accumulate = bool(enabled)
+
+
+def fused_grad_accumulation() -> bool:
+    return _fused_accumulate
 
 
 def is_async() -> bool:

@@ -41,9 +41,9 @@ int fail(int code, const std::string& msg)
 
 // ---- optional per-stage HIP-event timing (used by bench.py for the roofline figures) ----------
 enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_RENDER_FWD,
-             ST_GRAD_ZERO, ST_RENDER_BWD, ST_GAUSS_BWD, ST_COUNT };
+             ST_GRAD_ZERO, ST_RENDER_BWD, ST_OUT_ZERO, ST_GAUSS_BWD, ST_COUNT };
 const char* const kStageNames[ST_COUNT] = { "preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges",
-                                            "render_fwd", "grad_zero", "render_bwd", "gauss_bwd" };
+                                            "render_fwd", "grad_zero", "render_bwd", "out_zero", "gauss_bwd" };
 struct ProfRec { int stage; hipEvent_t e0, e1; };
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof_recs;
@@ -127,8 +127,9 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     uint32_t* gval_a = reinterpret_cast<uint32_t*>(geom + GL.val_a);
     uint32_t* gval_b = reinterpret_cast<uint32_t*>(geom + GL.val_b);
     uint32_t* offsets = reinterpret_cast<uint32_t*>(geom + GL.offsets);
-    uint32_t* scan_sums = reinterpret_cast<uint32_t*>(geom + GL.scan_sums);
+    uint2* scan_sums = reinterpret_cast<uint2*>(geom + GL.scan_sums);
     uint32_t* ghist = reinterpret_cast<uint32_t*>(geom + GL.hist);
+    uint32_t* tiles_ref = reinterpret_cast<uint32_t*>(geom + GL.tiles_ref);
     float* final_T = reinterpret_cast<float*>(img + IL.final_T);
     uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + IL.n_contrib);
     uint2* ranges = reinterpret_cast<uint2*>(img + IL.ranges);
@@ -156,7 +157,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
         // K1: cull / project / conic / colour -> GaussRec, radii, tile counts, depth keys
         { ProfScope ps(ST_PREPROCESS, s);
         launch_preprocess(vp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          prefiltered != 0, radii, rec, clamped, tiles_touched, gkey_a, hdr,
+                          prefiltered != 0, radii, rec, clamped, tiles_touched, tiles_ref, gkey_a, hdr,
                           (uint32_t)binning_capacity, s); }
         LR_DEBUG_SYNC(debug, s, "preprocess");
 
@@ -170,16 +171,18 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
 
         // exclusive scan of tile counts in depth order; total -> header
         { ProfScope ps(ST_SCAN, s);
-        launch_scan_tiles(P, order, tiles_touched, offsets, scan_sums, hdr, s); }
+        launch_scan_tiles(P, order, tiles_touched, tiles_ref, offsets, scan_sums, hdr, s); }
         LR_DEBUG_SYNC(debug, s, "scan");
 
         if (binning_capacity == 0) {
-            // exact mode: one 4-byte read-back, like rasterizer_impl.cu:281-282
-            uint32_t hostR = 0;
-            LR_HIP_CHECK(hipMemcpyAsync(&hostR, &hdr->num_rendered, 4, hipMemcpyDeviceToHost, s));
+            // exact mode: one small read-back, like rasterizer_impl.cu:281-282: the reference's num_rendered
+            // (returned to the caller) and the number of instances that survive exact tile culling
+            // (sizes the binning buffer)
+            uint32_t meta[8];
+            LR_HIP_CHECK(hipMemcpyAsync(meta, hdr, sizeof(meta), hipMemcpyDeviceToHost, s));
             LR_HIP_CHECK(hipStreamSynchronize(s));
-            R_bound = hostR;
-            num_rendered = (int)hostR;
+            R_bound = meta[6];
+            num_rendered = (int)meta[0];
         } else {
             R_bound = binning_capacity;
             num_rendered = LR_NUM_RENDERED_ON_DEVICE;
@@ -194,19 +197,24 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
         uint32_t* bval_b = reinterpret_cast<uint32_t*>(bin + BL.val_b);
         uint32_t* bhist = reinterpret_cast<uint32_t*>(bin + BL.hist);
 
+        // emit into the half from which `tile_passes` ping-pong passes end in (key_a, val_a)
+        uint32_t* ekey = (tile_passes & 1) ? bkey_b : bkey_a;
+        uint32_t* eval = (tile_passes & 1) ? bval_b : bval_a;
+        uint32_t* okey = (tile_passes & 1) ? bkey_a : bkey_b;
+        uint32_t* oval = (tile_passes & 1) ? bval_a : bval_b;
         if (R_bound > 0) {
             { ProfScope ps(ST_EMIT, s);
-            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, bkey_a, bval_a, s); }
+            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, ekey, eval, s); }
             LR_DEBUG_SYNC(debug, s, "emit");
             // stable partition by tile id: with the depth order of emission this is the reference's
             // (tile | depth) order (rasterizer_impl.cu:301-309)
             { ProfScope ps(ST_TILE_SORT, s);
-            radix_sort_pairs(bkey_a, bkey_b, bval_a, bval_b, /*iota*/ false, &hdr->num_sorted, R_bound, tile_bits,
+            radix_sort_pairs(ekey, okey, eval, oval, /*iota*/ false, &hdr->num_sorted, R_bound, tile_bits,
                              bhist, &inst_keys_sorted, &point_list, s); }
             LR_DEBUG_SYNC(debug, s, "tile sort");
         } else {
-            inst_keys_sorted = (tile_passes & 1) ? bkey_b : bkey_a;
-            point_list = (tile_passes & 1) ? bval_b : bval_a;
+            inst_keys_sorted = bkey_a;
+            point_list = bval_a;
         }
         { ProfScope ps(ST_RANGES, s);
         launch_ranges(inst_keys_sorted, hdr, R_bound, num_tiles, ranges, s); }
@@ -239,7 +247,8 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
                 float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
                 const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
-                float* dL_dscale, float* dL_drot, int debug, long long binning_capacity, void* stream_)
+                float* dL_dscale, float* dL_drot, int debug, long long binning_capacity,
+                unsigned int accumulate_mask, void* stream_)
 {
     using namespace lr;
     (void)dL_depths;   // ignored, as in the reference (backward.cu:457-464, 539-554 commented out)
@@ -260,15 +269,11 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + IL.n_contrib);
     const uint2* ranges = reinterpret_cast<const uint2*>(image_buffer + IL.ranges);
 
-    // The binning layout is a function of the size the forward allocated for: R (exact mode) or
-    // binning_capacity (async mode); the ping-pong half holding the final list depends only on the
-    // number of tile-sort passes.  No device read-back is needed here.
-    if (binning_capacity <= 0 && R < 0) return fail(LR_ERR_INVALID_ARG, "pass R (exact mode) or binning_capacity (async mode)");
-    const long long R_bound = binning_capacity > 0 ? binning_capacity : (long long)R;
-    const int tile_bits = bits_for((uint32_t)(gx * gy - 1));
-    const uint32_t which = (uint32_t)(((tile_bits + RADIX_BITS - 1) / RADIX_BITS) & 1);
-    const BinLayout BL = bin_layout(R_bound);
-    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer + (which ? BL.val_b : BL.val_a));
+    // The tile-sorted instance list always ends at offset 0 of the binning buffer (val_a), whatever
+    // R / capacity the forward used, so nothing has to be read back here (R and binning_capacity are
+    // accepted for symmetry with lr_forward).
+    (void)R; (void)binning_capacity;
+    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer);
 
     ViewParams vp;
     vp.view = viewmatrix; vp.proj = projmatrix; vp.campos = campos;
@@ -283,10 +288,20 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     { ProfScope ps(ST_RENDER_BWD, s);
     launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix, grad, s); }
     LR_DEBUG_SYNC(debug, s, "render backward");
+    {   // tensors in write mode are zero-filled here (one launch); accumulate-mode tensors are left alone
+        ProfScope ps(ST_OUT_ZERO, s);
+        const unsigned long long Pn = (unsigned long long)P;
+        float* ptrs[9] = { dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
+        const unsigned long long nf[9] = { 3 * Pn, 4 * Pn, Pn, 3 * Pn, 3 * Pn, 6 * Pn, (unsigned long long)M * 3 * Pn, 3 * Pn, 4 * Pn };
+        float* zp[9]; unsigned long long zn[9]; int zc = 0;
+        for (int k = 0; k < 9; k++)
+            if (ptrs[k] != nullptr && !((accumulate_mask >> k) & 1u)) { zp[zc] = ptrs[k]; zn[zc] = nf[k]; zc++; }
+        launch_zero_outputs(zp, zn, zc, s);
+    }
     { ProfScope ps(ST_GAUSS_BWD, s);
     launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, grad,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                     dL_drot, s); }
+                     dL_drot, accumulate_mask, s); }
     LR_DEBUG_SYNC(debug, s, "preprocess backward");
     LR_HIP_CHECK(hipGetLastError());
     return 0;

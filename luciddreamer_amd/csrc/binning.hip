@@ -192,30 +192,37 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_reduce(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-              uint32_t* __restrict__ block_sums)
+              const uint32_t* __restrict__ tiles_ref, uint2* __restrict__ block_sums)
 {
     __shared__ uint32_t s_tmp[4];
     const int base = blockIdx.x * SCAN_TILE;
-    uint32_t sum = 0;
+    uint32_t sum = 0, sum_ref = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         const int k = base + i * SCAN_THREADS + threadIdx.x;
-        if (k < P) sum += tiles_touched[order[k]];
+        if (k < P) { const uint32_t id = order[k]; sum += tiles_touched[id]; sum_ref += tiles_ref[id]; }
     }
     sum = block_reduce_sum(sum, s_tmp);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = sum;
+    sum_ref = block_reduce_sum(sum_ref, s_tmp);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint2(sum, sum_ref);
 }
 
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_scan_write(int P, const uint32_t* __restrict__ order, const uint32_t* __restrict__ tiles_touched,
-             const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ offsets, GeomHeader* hdr)
+             const uint2* __restrict__ block_sums, uint32_t* __restrict__ offsets, GeomHeader* hdr)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_wave[4];
-    // prefix of the preceding blocks' sums
-    uint32_t pre = 0;
-    for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_THREADS) pre += block_sums[i];
+    // prefix of the preceding blocks' sums; the last block also totals the reference counts
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    uint32_t pre = 0, ref_total = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += SCAN_THREADS) {
+        const uint2 v = block_sums[i];
+        if (i < (int)blockIdx.x) pre += v.x;
+        ref_total += v.y;
+    }
     pre = block_reduce_sum(pre, s_tmp);
+    if (last_block) ref_total = block_reduce_sum(ref_total, s_tmp);
 
     // blocked arrangement: thread t owns SCAN_ITEMS consecutive ranks
     const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
@@ -245,9 +252,10 @@ k_scan_write(int P, const uint32_t* __restrict__ order, const uint32_t* __restri
         if (k < P) offsets[k] = run;
         run += v[i];
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == SCAN_THREADS - 1) {
+    if (last_block && threadIdx.x == SCAN_THREADS - 1) {
         const uint32_t total = run;
-        hdr->num_rendered = total;
+        hdr->num_instances = total;
+        hdr->num_rendered = ref_total;
         const bool over = (hdr->capacity != 0 && total > hdr->capacity);
         hdr->overflow = over ? 1u : 0u;
         hdr->num_sorted = over ? hdr->capacity : total;
@@ -277,37 +285,64 @@ k_emit(int P, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t
     constexpr uint32_t SMALL = 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
     const uint32_t cap = hdr->capacity != 0 ? hdr->capacity : 0xFFFFFFFFu;
-    uint32_t idx = 0, tt = 0, off = 0;
+    uint32_t idx = 0, tt = 0, off = 0, area = 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
+    float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, qmax = 0.f, r_c = 0.f, r_a = 0.f;
     if (k < P) {
         idx = order[k];
-        tt = tiles_touched[idx];
+        tt = tiles_touched[idx];                   // instances to emit (after exact tile culling, preprocess.hip)
         if (tt != 0) {
             off = offsets[k];
-            const float2 xy = *reinterpret_cast<const float2*>(rec + idx);
-            tile_rect_dev(xy.x, xy.y, radii[idx], gx, gy, minx, miny, maxx, maxy);
+            const float4* g = reinterpret_cast<const float4*>(rec + idx);
+            const float4 q0 = g[0];
+            const float4 q1 = g[1];
+            const float4 q2 = g[2];
+            mx = q0.x; my = q0.y; ca = q0.z; cb = q0.w; cc = q1.x;
+            qmax = q2.z;                               // computed once in k_preprocess
+            r_c = -cb / cc; r_a = -cb / ca;
+            tile_rect_dev(mx, my, radii[idx], gx, gy, minx, miny, maxx, maxy);
+            area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
         }
     }
     const int rw = maxx - minx;
-    if (tt != 0 && tt <= SMALL) {
+    const bool culled = area <= CULL_MAX_TILES;   // same rule as the count in k_preprocess
+    if (tt != 0 && area <= SMALL) {
         uint32_t o = off;
         for (int y = miny; y < maxy; y++)
             for (int x = minx; x < maxx; x++) {
-                if (o < cap) { inst_keys[o] = (uint32_t)(y * gx + x); inst_vals[o] = idx; }
-                o++;
+                if (tile_hit(mx, my, ca, cb, cc, r_c, r_a, qmax, x, y)) {
+                    if (o < cap) { inst_keys[o] = (uint32_t)(y * gx + x); inst_vals[o] = idx; }
+                    o++;
+                }
             }
     }
-    uint64_t big = __ballot(tt > SMALL);
+    uint64_t big = __ballot(tt != 0 && area > SMALL);
     while (big) {
         const int src = __ffsll((long long)big) - 1;
         big &= big - 1;
-        const uint32_t b_idx = __shfl(idx, src), b_tt = __shfl(tt, src), b_off = __shfl(off, src);
+        const uint32_t b_idx = __shfl(idx, src), b_area = __shfl(area, src);
+        uint32_t b_off = __shfl(off, src);
         const int b_minx = __shfl(minx, src), b_miny = __shfl(miny, src), b_rw = __shfl(rw, src);
-        for (uint32_t j = lane; j < b_tt; j += 64) {
-            const int y = b_miny + (int)(j / (uint32_t)b_rw), x = b_minx + (int)(j % (uint32_t)b_rw);
-            const uint32_t o = b_off + j;
-            if (o < cap) { inst_keys[o] = (uint32_t)(y * gx + x); inst_vals[o] = b_idx; }
+        const bool b_culled = __shfl((int)culled, src) != 0;
+        const float b_mx = __shfl(mx, src), b_my = __shfl(my, src), b_ca = __shfl(ca, src), b_cb = __shfl(cb, src);
+        const float b_cc = __shfl(cc, src), b_qmax = __shfl(qmax, src);
+        const float b_rc = __shfl(r_c, src), b_ra = __shfl(r_a, src);
+        for (uint32_t j0 = 0; j0 < b_area; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            bool hit = j < b_area;
+            int y = 0, x = 0;
+            if (hit) {
+                y = b_miny + (int)(j / (uint32_t)b_rw); x = b_minx + (int)(j % (uint32_t)b_rw);
+                if (b_culled) hit = tile_hit(b_mx, b_my, b_ca, b_cb, b_cc, b_rc, b_ra, b_qmax, x, y);
+            }
+            const uint64_t m = __ballot(hit);
+            if (hit) {
+                const uint32_t o = b_off + (uint32_t)__popcll(m & lt);
+                if (o < cap) { inst_keys[o] = (uint32_t)(y * gx + x); inst_vals[o] = b_idx; }
+            }
+            b_off += (uint32_t)__popcll(m);
         }
     }
 }
@@ -361,11 +396,11 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
     *vals_out = vin;
 }
 
-void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* offsets,
-                       uint32_t* block_sums, GeomHeader* hdr, hipStream_t s)
+void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, const uint32_t* tiles_ref,
+                       uint32_t* offsets, uint2* block_sums, GeomHeader* hdr, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, P, order, tiles_touched, block_sums);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, P, order, tiles_touched, tiles_ref, block_sums);
     hipLaunchKernelGGL(k_scan_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, order, tiles_touched, block_sums,
                        offsets, hdr);
 }

@@ -18,7 +18,7 @@ constexpr int WAVE = 64;
 struct __attribute__((aligned(16))) GaussRec {
     float x, y, ca, cb;             // pixel-space mean, conic a, conic b
     float cc, opacity, r, g;        // conic c, opacity, colour r, g
-    float b, depth, pad0, pad1;     // colour b, view-space depth
+    float b, depth, qmax, pad1;     // colour b, view-space depth, log(255*opacity)+CULL_MARGIN (cull_qmax)
 };
 static_assert(sizeof(GaussRec) == 48, "GaussRec must be 48 bytes");
 
@@ -32,13 +32,15 @@ static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 
 // Header at offset 0 of the geom buffer (device-resident view state).
 struct GeomHeader {
-    uint32_t num_rendered;          // total tile instances R of this view (device-side truth)
-    uint32_t overflow;              // 1 if R exceeded the binning capacity (async mode)
+    uint32_t num_rendered;          // the reference's num_rendered: sum of tile-rectangle areas (reported to callers)
+    uint32_t overflow;              // 1 if num_instances exceeded the binning capacity (async mode)
     uint32_t prefilter_trap;        // 1 if a culled point was seen with prefiltered=true
     uint32_t capacity;              // binning capacity (instances)
     uint32_t P;
-    uint32_t num_sorted;            // min(num_rendered, capacity): length of the instance list actually built
-    uint32_t reserved[58];
+    uint32_t num_sorted;            // min(num_instances, capacity): length of the instance list actually built
+    uint32_t num_instances;         // tile instances after exact tile culling (what is emitted and sorted)
+    uint32_t unused0;
+    uint32_t reserved[56];
 };
 static_assert(sizeof(GeomHeader) == 256, "GeomHeader must be 256 bytes");
 
@@ -75,7 +77,7 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, key_a, key_b, val_a, val_b, offsets, scan_sums, hist, grad, total;
+    size_t header, rec, clamped, tiles_touched, key_a, key_b, val_a, val_b, offsets, scan_sums, hist, grad, tiles_ref, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -88,9 +90,10 @@ inline GeomLayout geom_layout(int P) {
     L.val_a = o;         o += align_up(Pz * 4);
     L.val_b = o;         o += align_up(Pz * 4);
     L.offsets = o;       o += align_up(Pz * 4);
-    L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 4);
+    L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
     L.hist = o;          o += sort_hist_bytes((long long)Pz);
     L.grad = o;          o += align_up(Pz * sizeof(GradRec));
+    L.tiles_ref = o;     o += align_up(Pz * 4);
     L.total = o;
     return L;
 }
@@ -106,14 +109,64 @@ inline ImgLayout img_layout(int W, int H) {
 }
 struct BinLayout { size_t key_a, key_b, val_a, val_b, hist, total; };
 inline BinLayout bin_layout(long long R) {
+    // val_a sits at offset 0 and always receives the final tile-sorted list (the emit target is chosen by
+    // the parity of the number of sort passes), so the backward finds it without knowing R.
     BinLayout L; size_t o = 0; size_t Rz = R > 0 ? (size_t)R : 1;
-    L.key_a = o; o += align_up(Rz * 4);
-    L.key_b = o; o += align_up(Rz * 4);
     L.val_a = o; o += align_up(Rz * 4);
     L.val_b = o; o += align_up(Rz * 4);
+    L.key_a = o; o += align_up(Rz * 4);
+    L.key_b = o; o += align_up(Rz * 4);
     L.hist = o;  o += sort_hist_bytes((long long)Rz);
     L.total = o;
     return L;
+}
+
+// ---- exact tile culling ------------------------------------------------------------------------
+// A (Gaussian, tile) pair can only matter if some pixel of the tile reaches alpha >= 1/255, i.e. if
+// q(d) = 0.5*(a dx^2 + c dy^2) + b dx dy <= log(255*opacity) somewhere on the tile's 16x16 pixel centres.
+// tile_hit() minimises the convex quadratic q over the tile's box of offsets exactly (interior or one of
+// the four edges) and keeps the pair unless the minimum exceeds log(255*o) + CULL_MARGIN.  The margin is
+// orders of magnitude above the float rounding of q / exp, and the blend kernels reject per pixel with the
+// smaller margin 0.01, so dropping the pair can never change a pixel.  The reference emits one instance
+// per tile of the 3-sigma bounding SQUARE (auxiliary.h:46-56, rasterizer_impl.cu:85-109); the instances
+// dropped here are exactly ones its per-pixel `alpha < 1/255 -> continue` (forward.cu:338-339) skips.
+constexpr float CULL_MARGIN = 0.02f;
+constexpr uint32_t CULL_MAX_TILES = 96;       // larger rectangles are emitted unculled (bounded per-lane loop)
+
+// Minimum-of-quadratic test on an axis-aligned box of pixel centres [x_lo,x_hi] x [y_lo,y_hi].
+// r_c = -cb/cc and r_a = -cb/ca are the slopes of the edge-constrained minimisers (one division each per
+// Gaussian, not per box).  Evaluated by k_preprocess (count), k_emit (emission) -- which must agree bit for
+// bit whatever the contraction setting of the translation unit -- and by the blend kernels per 8x8 quadrant.
+__device__ __forceinline__ bool box_hit(float mx, float my, float ca, float cb, float cc, float r_c, float r_a,
+                                        float qmax, float x_lo, float x_hi, float y_lo, float y_hi)
+{
+#pragma clang fp contract(off)
+    const float dx_lo = mx - x_hi, dx_hi = mx - x_lo;
+    const float dy_lo = my - y_hi, dy_hi = my - y_lo;
+    if (dx_lo <= 0.f && dx_hi >= 0.f && dy_lo <= 0.f && dy_hi >= 0.f) return true;
+    if (!(ca > 0.f) || !(cc > 0.f)) return true;              // not a proper ellipse: keep (conservative)
+    float qmin = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float ex = k ? dx_hi : dx_lo;
+        const float ys = fminf(dy_hi, fmaxf(dy_lo, r_c * ex));
+        qmin = fminf(qmin, 0.5f * (ca * ex * ex + cc * ys * ys) + cb * ex * ys);
+        const float ey = k ? dy_hi : dy_lo;
+        const float xs = fminf(dx_hi, fmaxf(dx_lo, r_a * ey));
+        qmin = fminf(qmin, 0.5f * (ca * xs * xs + cc * ey * ey) + cb * xs * ey);
+    }
+    return !(qmin > qmax);                                     // NaN anywhere -> keep
+}
+__device__ __forceinline__ bool tile_hit(float mx, float my, float ca, float cb, float cc, float r_c, float r_a,
+                                         float qmax, int tx, int ty)
+{
+    return box_hit(mx, my, ca, cb, cc, r_c, r_a, qmax, (float)(tx * TILE_X), (float)(tx * TILE_X + TILE_X - 1),
+                   (float)(ty * TILE_Y), (float)(ty * TILE_Y + TILE_Y - 1));
+}
+// log(255*o) + margin; opacity <= 0 can never reach 1/255: every tile is dropped (-inf).
+__device__ __forceinline__ float cull_qmax(float opacity)
+{
+    return (opacity > 0.f) ? (logf(255.0f * opacity) + CULL_MARGIN) : -3.0e38f;
 }
 
 // ---- launchers (one per translation unit) ------------------------------------------------------
@@ -128,8 +181,8 @@ struct ViewParams {
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key, GeomHeader* hdr,
-                       uint32_t binning_capacity, hipStream_t s);
+                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* tiles_ref, uint32_t* depth_key,
+                       GeomHeader* hdr, uint32_t binning_capacity, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
                          hipStream_t s);
 
@@ -140,10 +193,10 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
                       const uint32_t* n_dev, long long n_bound, int end_bit, uint32_t* hist,
                       uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
 
-// offsets[k] = exclusive prefix of tiles_touched[order[k]], k in depth order; total -> hdr->num_rendered
-// (and the overflow flag against hdr->capacity).
-void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, uint32_t* offsets,
-                       uint32_t* block_sums, GeomHeader* hdr, hipStream_t s);
+// offsets[k] = exclusive prefix of tiles_touched[order[k]], k in depth order; total -> hdr->num_instances
+// (and the overflow flag against hdr->capacity); sum of tiles_ref -> hdr->num_rendered (reference count).
+void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, const uint32_t* tiles_ref,
+                       uint32_t* offsets, uint2* block_sums, GeomHeader* hdr, hipStream_t s);
 void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* offsets,
                  const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                  uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t s);
@@ -161,7 +214,11 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       const int* radii, const uint8_t* clamped, const GradRec* grad,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      hipStream_t s);
+                      uint32_t accum_mask, hipStream_t s);
+// bit positions of lr_backward's accumulate_mask (LR_ACC_* in lucid_raster.h)
+enum { ACC_MEAN2D = 0, ACC_CONIC = 1, ACC_OPACITY = 2, ACC_COLOR = 3, ACC_MEAN3D = 4, ACC_COV3D = 5, ACC_SH = 6,
+       ACC_SCALE = 7, ACC_ROT = 8 };
+void launch_zero_outputs(float* const* ptrs, const unsigned long long* nfloats, int count, hipStream_t s);
 
 void launch_dist2(int P, const float* points, float* out, char* workspace, hipStream_t s);
 size_t dist2_workspace_bytes(int P);

@@ -4,9 +4,14 @@
 // preprocessCUDA (:346-396) with its helpers computeColorFromSH (:20-139) and computeCov3D
 // (:278-341) -- fused into ONE streaming pass: read the 48-byte GradRec produced by the blend
 // backward, recompute the forward intermediates from the inputs (cheaper than storing cov3D /
-// re-reading it: HBM-bound kernel), and write every gradient row exactly once.  Rows of culled
-// Gaussians are written as zeros here, so the caller never has to zero-fill the nine output
-// tensors (the reference memsets 300 B/Gaussian per backward, rasterize_points.cu:154-162).
+// re-reading it: HBM-bound kernel).  Only visible Gaussians (radii > 0) do any work or touch memory.
+// Two output modes per tensor (bit in `accum_mask`):
+//   write      : rows of visible Gaussians are stored; the library zero-fills the tensor first with one
+//                multi-segment kernel (k_zero_segments), so callers still never pre-zero anything
+//                (the reference memsets 300 B/Gaussian per backward, rasterize_points.cu:154-162);
+//   accumulate : rows of visible Gaussians are ADDED to what is already there and culled rows are not
+//                touched at all -- this fuses autograd's `grad += new_grad` pass (another 3 x 236 B per
+//                Gaussian per view of HBM traffic) into the kernel when several views are accumulated.
 #include "common.h"
 
 namespace lr {
@@ -114,17 +119,17 @@ __device__ __forceinline__ V3 sh_backward(const float* __restrict__ sh_row, V3 d
     return { dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB) };
 }
 
-__global__ void __launch_bounds__(256)
-k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
+// Backward of ONE visible Gaussian.
+__device__ __forceinline__ void
+gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
-            const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
+            const float* __restrict__ cov3D_precomp,
             const uint8_t* __restrict__ clamped, const GradRec* __restrict__ grad,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot)
+            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+            uint32_t accum_mask)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= vp.P) return;
     const size_t i = (size_t)idx;
     const float* __restrict__ V = vp.view;
     const float* __restrict__ Pm = vp.proj;
@@ -138,7 +143,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
 #pragma unroll
     for (int k = 0; k < 48; k++) dsh[k] = 0.f;
 
-    if (radii[idx] > 0) {
+    {
         const float4* gp = reinterpret_cast<const float4*>(grad + i);
         const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
         const float gmx = g0.x, gmy = g0.y;                 // dL/dmean2D
@@ -291,40 +296,153 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         }
     }
 
-    // ---- write every row exactly once ----
-    dL_dmean2D[3 * i] = o_m2d[0]; dL_dmean2D[3 * i + 1] = o_m2d[1]; dL_dmean2D[3 * i + 2] = 0.f;
-    if (dL_dconic != nullptr)
-        reinterpret_cast<float4*>(dL_dconic)[idx] = make_float4(o_conic[0], o_conic[1], 0.f, o_conic[3]);
-    dL_dopacity[idx] = o_op;
-    dL_dcolor[3 * i] = o_col[0]; dL_dcolor[3 * i + 1] = o_col[1]; dL_dcolor[3 * i + 2] = o_col[2];
-    dL_dmean3D[3 * i] = o_m3d[0]; dL_dmean3D[3 * i + 1] = o_m3d[1]; dL_dmean3D[3 * i + 2] = o_m3d[2];
+    // ---- store (or accumulate) the rows of this visible Gaussian ----
+#define LR_OUT(bit, ptr, val) do { float* p__ = (ptr); *p__ = ((accum_mask >> (bit)) & 1u) ? (*p__ + (val)) : (val); } while (0)
+    LR_OUT(ACC_MEAN2D, dL_dmean2D + 3 * i, o_m2d[0]); LR_OUT(ACC_MEAN2D, dL_dmean2D + 3 * i + 1, o_m2d[1]);
+    if (!((accum_mask >> ACC_MEAN2D) & 1u)) dL_dmean2D[3 * i + 2] = 0.f;
+    if (dL_dconic != nullptr) {
+        LR_OUT(ACC_CONIC, dL_dconic + 4 * i, o_conic[0]); LR_OUT(ACC_CONIC, dL_dconic + 4 * i + 1, o_conic[1]);
+        LR_OUT(ACC_CONIC, dL_dconic + 4 * i + 3, o_conic[3]);
+    }
+    LR_OUT(ACC_OPACITY, dL_dopacity + i, o_op);
 #pragma unroll
-    for (int k = 0; k < 6; k++) dL_dcov3D[6 * i + k] = o_cov[k];
-    dL_dscale[3 * i] = o_scale[0]; dL_dscale[3 * i + 1] = o_scale[1]; dL_dscale[3 * i + 2] = o_scale[2];
-    reinterpret_cast<float4*>(dL_drot)[idx] = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+    for (int k = 0; k < 3; k++) LR_OUT(ACC_COLOR, dL_dcolor + 3 * i + k, o_col[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) LR_OUT(ACC_MEAN3D, dL_dmean3D + 3 * i + k, o_m3d[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) LR_OUT(ACC_COV3D, dL_dcov3D + 6 * i + k, o_cov[k]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) LR_OUT(ACC_SCALE, dL_dscale + 3 * i + k, o_scale[k]);
+    {
+        float4* pr = reinterpret_cast<float4*>(dL_drot) + idx;
+        float4 v = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
+        if ((accum_mask >> ACC_ROT) & 1u) { const float4 o = *pr; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *pr = v;
+    }
+#undef LR_OUT
     if (dL_dsh != nullptr && shrow > 0) {
-        if (shrow <= 48) store_row<48>(dL_dsh + i * shrow, dsh, shrow);
-        else {
-            float* dst = dL_dsh + i * shrow;
-            for (int k = 0; k < shrow; k++) dst[k] = (k < 48) ? dsh[k] : 0.f;
+        float* dst = dL_dsh + i * shrow;
+        const int nk = 3 * (vp.D + 1) * (vp.D + 1);            // only the active bands are non-zero
+        const bool acc = (accum_mask >> ACC_SH) & 1u;
+        if ((shrow & 3) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                if (4 * q < nk) {
+                    float4 v = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
+                    float4* pq = reinterpret_cast<float4*>(dst) + q;
+                    if (acc) { const float4 o = *pq; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                    *pq = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 48; k++)
+                if (k < nk) dst[k] = acc ? dst[k] + dsh[k] : dsh[k];
         }
     }
 }
 
+// Each workgroup owns CHUNK consecutive Gaussians: it compacts the visible ones (radii > 0) into LDS and
+// then runs the heavy per-Gaussian backward with DENSE waves over that list.  With few visible Gaussians
+// (camera paths see ~10 % of a scene) a thread-per-Gaussian launch would run the full 200-VGPR body in
+// every wave for a handful of live lanes; here the body runs once per CHUNK/64 as many Gaussians, index
+// order (and with it coalescing of the row reads/writes) is preserved, and no global atomics are needed.
+constexpr int GB_CHUNK = 1024;
+
+__global__ void __launch_bounds__(256)
+k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
+            const float* __restrict__ rotations, const float* __restrict__ shs,
+            const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
+            const uint8_t* __restrict__ clamped, const GradRec* __restrict__ grad,
+            float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+            float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
+            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+            uint32_t accum_mask)
+{
+    __shared__ uint32_t s_list[GB_CHUNK];
+    __shared__ uint32_t s_count;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    const int base = blockIdx.x * GB_CHUNK;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int r = 0; r < GB_CHUNK / 256; r++) {
+        const int idx = base + r * 256 + (int)threadIdx.x;
+        const bool vis = idx < vp.P && radii[idx] > 0;
+        const uint64_t m = __ballot(vis);
+        uint32_t pos = 0;
+        if (lane == 0 && m != 0) pos = atomicAdd(&s_count, (uint32_t)__popcll(m));
+        pos = __shfl(pos, 0);
+        if (vis) s_list[pos + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+    }
+    __syncthreads();
+    const uint32_t n = s_count;
+    for (uint32_t t = threadIdx.x; t < n; t += 256)
+        gauss_backward_one((int)s_list[t], vp, means3D, scales, rotations, shs, cov3D_precomp, clamped, grad,
+                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                           dL_drot, accum_mask);
+}
+
+struct ZeroSegs { float4* p[9]; unsigned long long n4[9]; unsigned long long off[10]; int count; };
+
+// One launch zero-fills up to nine output tensors (16-byte stores, grid-stride over the concatenation).
+__global__ void __launch_bounds__(256)
+k_zero_segments(ZeroSegs z)
+{
+    const unsigned long long total = z.off[z.count];
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (unsigned long long)gridDim.x * blockDim.x) {
+        int sgi = 0;
+#pragma unroll
+        for (int k = 1; k < 9; k++) if (k < z.count && t >= z.off[k]) sgi = k;
+        z.p[sgi][t - z.off[sgi]] = zero;
+    }
+}
+
+__global__ void k_zero_tail(float* p, unsigned long long from, unsigned long long to)
+{
+    const unsigned long long t = from + (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < to) p[t] = 0.f;
+}
+
 }  // namespace
+
+void launch_zero_outputs(float* const* ptrs, const unsigned long long* nfloats, int count, hipStream_t s)
+{
+    ZeroSegs z;
+    z.count = 0;
+    z.off[0] = 0;
+    for (int k = 0; k < count && z.count < 9; k++) {
+        if (ptrs[k] == nullptr || nfloats[k] == 0) continue;
+        const unsigned long long n4 = nfloats[k] / 4;          // all torch allocations are >= 16-byte aligned
+        if (nfloats[k] % 4) hipLaunchKernelGGL(k_zero_tail, dim3(1), dim3(64), 0, s, ptrs[k], n4 * 4, nfloats[k]);
+        if (n4 == 0) continue;
+        z.p[z.count] = reinterpret_cast<float4*>(ptrs[k]);
+        z.n4[z.count] = n4;
+        z.off[z.count + 1] = z.off[z.count] + n4;
+        z.count++;
+    }
+    if (z.count == 0) return;
+    for (int k = z.count; k < 9; k++) { z.p[k] = nullptr; z.n4[k] = 0; z.off[k + 1] = z.off[z.count]; }
+    const unsigned long long total = z.off[z.count];
+    unsigned long long blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_zero_segments, dim3((unsigned)blocks), dim3(256), 0, s, z);
+}
 
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                       const int* radii, const uint8_t* clamped, const GradRec* grad,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      hipStream_t s)
+                      uint32_t accum_mask, hipStream_t s)
 {
     (void)colors_precomp;
     if (vp.P <= 0) return;
-    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + 255) / 256), dim3(256), 0, s, vp, means3D, scales, rotations, shs,
+    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + GB_CHUNK - 1) / GB_CHUNK), dim3(256), 0, s, vp, means3D, scales, rotations, shs,
                        cov3D_precomp, radii, clamped, grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
 }
 
 }  // namespace lr

@@ -130,26 +130,29 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
              const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
              const float* __restrict__ colors_precomp, int prefiltered,
              int* __restrict__ radii, GaussRec* __restrict__ rec, uint8_t* __restrict__ clamped,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ depth_key, GeomHeader* hdr,
-             uint32_t binning_capacity)
+             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tiles_ref,
+             uint32_t* __restrict__ depth_key, GeomHeader* hdr, uint32_t binning_capacity)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= vp.P) return;
+    const bool live = idx < vp.P;
     if (idx == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
     const float* __restrict__ V = vp.view;
     const float* __restrict__ Pm = vp.proj;
 
     int radius_out = 0;
-    uint32_t tiles_out = 0;
+    uint32_t tiles_out = 0;               // tile instances this Gaussian will emit (after exact tile culling)
+    uint32_t area_ref = 0;                // the reference's tiles_touched (rectangle area)
     uint32_t key_out = 0xFFFFFFFFu;       // culled Gaussians sort to the end and emit nothing
 
-    const float px_w = means3D[3 * (size_t)idx], py_w = means3D[3 * (size_t)idx + 1], pz_w = means3D[3 * (size_t)idx + 2];
+    const size_t li = live ? (size_t)idx : 0;
+    const float px_w = means3D[3 * li], py_w = means3D[3 * li + 1], pz_w = means3D[3 * li + 2];
     // view-space point (auxiliary.h:58-66) and the near cull z <= 0.2 (auxiliary.h:152-162)
     const float vx = V[0] * px_w + V[4] * py_w + V[8] * pz_w + V[12];
     const float vy = V[1] * px_w + V[5] * py_w + V[9] * pz_w + V[13];
     const float vz = V[2] * px_w + V[6] * py_w + V[10] * pz_w + V[14];
 
     do {
+        if (!live) break;
         if (vz <= 0.2f) {
             if (prefiltered) hdr->prefilter_trap = 1;
             break;
@@ -232,19 +235,33 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         GaussRec g;
         g.x = pix; g.y = piy; g.ca = con_a; g.cb = con_b;
         g.cc = con_c; g.opacity = opacities[idx]; g.r = rgb.x; g.g = rgb.y;
-        g.b = rgb.z; g.depth = vz; g.pad0 = 0.f; g.pad1 = 0.f;
+        g.b = rgb.z; g.depth = vz; g.qmax = cull_qmax(g.opacity); g.pad1 = 0.f;
         float4* dst = reinterpret_cast<float4*>(rec + idx);
         dst[0] = make_float4(g.x, g.y, g.ca, g.cb);
         dst[1] = make_float4(g.cc, g.opacity, g.r, g.g);
-        dst[2] = make_float4(g.b, g.depth, 0.f, 0.f);
+        dst[2] = make_float4(g.b, g.depth, g.qmax, 0.f);
 
         radius_out = (int)my_radius;
-        tiles_out = area;
+        area_ref = area;
         key_out = __float_as_uint(vz);                         // vz > 0.2: bit order == float order
+        // exact tile culling (common.h): count the tiles of the rectangle that can actually matter
+        if (area > CULL_MAX_TILES) {
+            tiles_out = area;
+        } else {
+            const float qmax = g.qmax;
+            const float r_c = -con_b / con_c, r_a = -con_b / con_a;
+            uint32_t cnt = 0;
+            for (int ty = miny; ty < maxy; ty++)
+                for (int tx = minx; tx < maxx; tx++)
+                    cnt += tile_hit(pix, piy, con_a, con_b, con_c, r_c, r_a, qmax, tx, ty) ? 1u : 0u;
+            tiles_out = cnt;
+        }
     } while (false);
 
+    if (!live) return;
     radii[idx] = radius_out;
     tiles_touched[idx] = tiles_out;
+    tiles_ref[idx] = area_ref;
     depth_key[idx] = key_out;
 }
 
@@ -263,14 +280,14 @@ k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key, GeomHeader* hdr,
-                       uint32_t binning_capacity, hipStream_t s)
+                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* tiles_ref, uint32_t* depth_key,
+                       GeomHeader* hdr, uint32_t binning_capacity, hipStream_t s)
 {
     if (vp.P <= 0) return;
     dim3 grid((vp.P + 255) / 256), block(256);
     hipLaunchKernelGGL(k_preprocess, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                        cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                       depth_key, hdr, binning_capacity);
+                       tiles_ref, depth_key, hdr, binning_capacity);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,

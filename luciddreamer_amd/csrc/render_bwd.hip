@@ -3,16 +3,20 @@
 // Replaces BACKWARD::render / renderCUDA (RAST/cuda_rasterizer/backward.cu:399-586).  The
 // per-pixel recursion is the reference's (back-to-front, T un-blended by division, colour
 // recursion through accum_rec, background term, 0.99 clamp not differentiated, depth gradient
-// ignored).  What differs is how the nine per-(pixel,Gaussian) gradient terms reach memory:
+// ignored).  The kernel is VALU-issue bound; the design removes wave-instructions:
 //
-//   reference: 9 global float atomicAdd per contributing pixel x Gaussian pair (:537-583)
-//   here:      wave64 DPP reduction (quad_perm / row_mirror / row_bcast, no LDS traffic)
-//              -> one LDS float add per term per wave into a per-batch accumulator
-//              -> one global atomic per term per Gaussian per TILE, issued by 256 threads in
-//                 parallel into one 48-byte GradRec (a single cache line) instead of four arrays.
-//   That is 256x fewer global atomics, and Gaussians no pixel of the wave can reach (same
-//   conservative exponent test as the forward) or that lie behind every pixel's last contributor
-//   are skipped wave-uniformly before any of that work.
+//   * same two-level loop as the forward: per 64 staged Gaussians one lane each runs the exact
+//     quadrant test (box_hit) -> 64-bit candidate mask; only candidates (walked back to front with
+//     s_flbit) are evaluated per pixel.  Positions at or behind the wave's deepest last contributor
+//     are masked out up front (backward.cu:500-502, made wave-uniform).
+//   * the nine per-(pixel,Gaussian) gradient terms reach memory as
+//       reference: 9 global float atomicAdd per contributing pixel x Gaussian pair (:537-583)
+//       here:      wave64 reduction of 8 terms with v_permlane32_swap / v_permlane16_swap (each swap+add
+//                  halves TWO terms at once) + 4 DPP steps inside the 16-lane rows = 20 instructions
+//                  (a per-term DPP tree costs 48 + hazards nops), 9th term by DPP;
+//                  -> 3 LDS float-add instructions per wave (4+4+1 lanes) into a per-batch accumulator
+//                  -> one global atomic per term per Gaussian per TILE, issued by 256 threads in
+//                     parallel into one 48-byte GradRec instead of four arrays.
 #include "common.h"
 
 namespace lr {
@@ -26,7 +30,7 @@ __device__ __forceinline__ float dpp(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-// Sum over the 64 lanes; the total is valid in lanes 48..63 (read it from lane 63).
+// Sum over the 64 lanes; the total is valid in lanes 48..63.
 __device__ __forceinline__ float wave_sum_hi(float v)
 {
     v += dpp<0xB1>(v);            // quad_perm [1,0,3,2]
@@ -36,6 +40,38 @@ __device__ __forceinline__ float wave_sum_hi(float v)
     v += dpp<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
     v += dpp<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
     return v;
+}
+// sum within each 16-lane row; every lane of the row ends with the row total
+__device__ __forceinline__ float row_sum(float v)
+{
+    v += dpp<0xB1>(v);
+    v += dpp<0x4E>(v);
+    v += dpp<0x141>(v);
+    v += dpp<0x140>(v);
+    return v;
+}
+// x <- (lanes 0-31: x[l] + x[l+32]) | (lanes 32-63: y[l-32] + y[l]): one swap + one add halves two terms
+// (inline asm: with ROCm 7.2 hipcc, __builtin_amdgcn_permlane32_swap followed by r[0] + r[1] returned
+//  2 * r[0] -- verified on hardware; "s_nop 1" covers the VALU-write -> v_permlane read hazard)
+__device__ __forceinline__ float fold32(float x, float y)
+{
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+// rows: [x0+x1, y0+y1, x2+x3, y2+y3]
+__device__ __forceinline__ float fold16(float x, float y)
+{
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+    return x + y;
+}
+// Reduce four per-lane terms over the wave.  Result: 16-lane row r holds the total of term ROWMAP[r],
+// ROWMAP = {v0, v2, v1, v3}.
+__device__ __forceinline__ float reduce4(float v0, float v1, float v2, float v3)
+{
+    const float s01 = fold32(v0, v1);        // lanes<32: v0 partials, lanes>=32: v1 partials
+    const float s23 = fold32(v2, v3);
+    const float t = fold16(s01, s23);        // rows: v0, v2, v1, v3
+    return row_sum(t);
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -50,6 +86,7 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
     return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 }
 
+// s_acc column of each term: 0 dmx, 1 dmy, 2 dca, 3 dcb, 4 dcc, 5 dop, 6 dr, 7 dg, 8 db (= GradRec float order)
 __global__ void __launch_bounds__(256)
 k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
@@ -58,20 +95,23 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              GradRec* __restrict__ grad)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, conic a, conic b
-    __shared__ float4 s_q1[BATCH];      // conic c, reject threshold, opacity, -
+    __shared__ float4 s_q1[BATCH];      // conic c, qmax, opacity, -
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
+    __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (4 waves add into it)
     __shared__ uint32_t s_touched[BATCH];
+    __shared__ uint32_t s_wlast[4];
 
     const int tile = swizzled_tile(num_tiles);
     if (tile >= num_tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int px = tx * TILE_X + (w & 1) * 8 + (l & 7);
-    const int py = ty * TILE_Y + (w >> 1) * 8 + (l >> 3);
+    const int qx = tx * TILE_X + (w & 1) * 8, qy = ty * TILE_Y + (w >> 1) * 8;
+    const int px = qx + (l & 7), py = qy + (l >> 3);
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
+    const float bx0 = (float)qx, bx1 = (float)(qx + 7), by0 = (float)qy, by1 = (float)(qy + 7);
     const size_t pix = (size_t)py * W + px;
     const size_t N = (size_t)W * H;
 
@@ -81,7 +121,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const float T_final = inside ? final_Ts[pix] : 0.f;
     float T = T_final;
     const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const uint32_t wave_last = wave_max_u32(last_contributor);       // nothing behind this matters to the wave
+    const uint32_t wave_last = wave_max_u32(last_contributor);       // nothing at or behind this matters to the wave
     float dLr = 0.f, dLg = 0.f, dLb = 0.f;
     if (inside) { dLr = dL_dpix[pix]; dLg = dL_dpix[N + pix]; dLb = dL_dpix[2 * N + pix]; }
     const float bg_dot = bg[0] * dLr + bg[1] * dLg + bg[2] * dLb;
@@ -91,10 +131,15 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const float ddely_dy = (float)(0.5 * H);
 
     // block-uniform: the deepest contributor of any pixel in the tile; batches entirely behind it are skipped
-    __shared__ uint32_t s_wlast[4];
     if (l == 0) s_wlast[w] = wave_last;
     __syncthreads();
     const uint32_t tile_last = max(max(s_wlast[0], s_wlast[1]), max(s_wlast[2], s_wlast[3]));
+
+    // LDS column written by this lane after the reductions: rows of reduce4 hold terms {v0, v2, v1, v3}
+    const int row = l >> 4;
+    const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // reduce4(dmx, dmy, dca, dcb)
+    const int col_b = (row == 0) ? 4 : (row == 1) ? 6 : (row == 2) ? 5 : 7;     // reduce4(dcc, dop, dr, dg)
+    const bool row_leader = (l & 15) == 0;
 
     for (int base = 0; base < total; base += BATCH) {
         // staged element i <-> list position pos = total-1-base-i (back to front)
@@ -107,10 +152,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const uint32_t id = point_list[range.x + (pos_hi - tid)];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            const float thr = -__logf(255.0f * b.y) - 0.01f;
             s_q0[tid] = a;
-            s_q1[tid] = make_float4(b.x, thr, b.y, 0.f);
+            s_q1[tid] = make_float4(b.x, c.z, b.y, 0.f);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
+            s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = id;
         }
 #pragma unroll
@@ -118,62 +163,70 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         s_touched[tid] = 0;
         __syncthreads();
 
-        for (int j = 0; j < cnt; j++) {
-            const uint32_t pos = (uint32_t)(pos_hi - j);
-            if (pos >= wave_last) continue;               // wave-uniform (backward.cu:500-502)
-            const float4 a = s_q0[j];
-            const float4 b = s_q1[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const bool cand = pos < last_contributor && power <= 0.0f && power >= b.y;
-            if (__ballot(cand) == 0) continue;
-
-            float g_dmx = 0.f, g_dmy = 0.f, g_dca = 0.f, g_dcb = 0.f, g_dcc = 0.f, g_dop = 0.f;
-            float g_dr = 0.f, g_dg = 0.f, g_db = 0.f;
-            bool contrib = false;
-            if (cand) {
-                const float G = expf(power);
-                const float alpha = fminf(0.99f, b.z * G);
-                if (alpha >= 1.0f / 255.0f) {
-                    contrib = true;
-                    const float4 c = s_q2[j];
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dalpha = 0.f;
-                    acr = last_alpha * lcr + (1.f - last_alpha) * acr; lcr = c.x;
-                    dL_dalpha += (c.x - acr) * dLr; g_dr = dchannel_dcolor * dLr;
-                    acg = last_alpha * lcg + (1.f - last_alpha) * acg; lcg = c.y;
-                    dL_dalpha += (c.y - acg) * dLg; g_dg = dchannel_dcolor * dLg;
-                    acb = last_alpha * lcb + (1.f - last_alpha) * acb; lcb = c.z;
-                    dL_dalpha += (c.z - acb) * dLb; g_db = dchannel_dcolor * dLb;
-                    dL_dalpha *= T;
-                    last_alpha = alpha;
-                    dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-
-                    const float dL_dG = b.z * dL_dalpha;
-                    const float gdx = G * dx, gdy = G * dy;
-                    const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                    const float dG_ddely = -gdy * b.x - gdx * a.w;
-                    g_dmx = dL_dG * dG_ddelx * ddelx_dx;
-                    g_dmy = dL_dG * dG_ddely * ddely_dy;
-                    g_dca = -0.5f * gdx * dx * dL_dG;
-                    g_dcb = -0.5f * gdx * dy * dL_dG;
-                    g_dcc = -0.5f * gdy * dy * dL_dG;
-                    g_dop = G * dL_dalpha;
+        for (int sb = 0; sb < cnt; sb += 64) {
+            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the quadrant
+            bool hit = false;
+            {
+                const int j = sb + l;
+                if (j < cnt && (uint32_t)(pos_hi - j) < wave_last) {
+                    const float4 a = s_q0[j];
+                    const float4 b = s_q1[j];
+                    const float2 r = s_q3[j];
+                    hit = box_hit(a.x, a.y, a.z, a.w, b.x, r.x, r.y, b.y, bx0, bx1, by0, by1);
                 }
             }
-            if (__ballot(contrib) == 0) continue;
-            g_dmx = wave_sum_hi(g_dmx); g_dmy = wave_sum_hi(g_dmy);
-            g_dca = wave_sum_hi(g_dca); g_dcb = wave_sum_hi(g_dcb); g_dcc = wave_sum_hi(g_dcc);
-            g_dop = wave_sum_hi(g_dop);
-            g_dr = wave_sum_hi(g_dr); g_dg = wave_sum_hi(g_dg); g_db = wave_sum_hi(g_db);
-            if (l == 63) {
+            uint64_t mask = __ballot(hit);
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
+                mask &= mask - 1;
+                const int j = sb + k;
+                const uint32_t pos = (uint32_t)(pos_hi - j);
+                const float4 a = s_q0[j];
+                const float4 b = s_q1[j];
+                const float dx = a.x - pxf, dy = a.y - pyf;
+                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+
+                float g_dmx = 0.f, g_dmy = 0.f, g_dca = 0.f, g_dcb = 0.f, g_dcc = 0.f, g_dop = 0.f;
+                float g_dr = 0.f, g_dg = 0.f, g_db = 0.f;
+                bool contrib = false;
+                if (pos < last_contributor && power <= 0.0f) {
+                    const float G = expf(power);
+                    const float alpha = fminf(0.99f, b.z * G);
+                    if (alpha >= 1.0f / 255.0f) {
+                        contrib = true;
+                        const float4 c = s_q2[j];
+                        T = T / (1.f - alpha);
+                        const float dchannel_dcolor = alpha * T;
+                        float dL_dalpha = 0.f;
+                        acr = last_alpha * lcr + (1.f - last_alpha) * acr; lcr = c.x;
+                        dL_dalpha += (c.x - acr) * dLr; g_dr = dchannel_dcolor * dLr;
+                        acg = last_alpha * lcg + (1.f - last_alpha) * acg; lcg = c.y;
+                        dL_dalpha += (c.y - acg) * dLg; g_dg = dchannel_dcolor * dLg;
+                        acb = last_alpha * lcb + (1.f - last_alpha) * acb; lcb = c.z;
+                        dL_dalpha += (c.z - acb) * dLb; g_db = dchannel_dcolor * dLb;
+                        dL_dalpha *= T;
+                        last_alpha = alpha;
+                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+
+                        const float dL_dG = b.z * dL_dalpha;
+                        const float gdx = G * dx, gdy = G * dy;
+                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+                        const float dG_ddely = -gdy * b.x - gdx * a.w;
+                        g_dmx = dL_dG * dG_ddelx * ddelx_dx;
+                        g_dmy = dL_dG * dG_ddely * ddely_dy;
+                        g_dca = -0.5f * gdx * dx * dL_dG;
+                        g_dcb = -0.5f * gdx * dy * dL_dG;
+                        g_dcc = -0.5f * gdy * dy * dL_dG;
+                        g_dop = G * dL_dalpha;
+                    }
+                }
+                if (__ballot(contrib) == 0) continue;
+                const float ra = reduce4(g_dmx, g_dmy, g_dca, g_dcb);     // rows: dmx, dca, dmy, dcb
+                const float rb = reduce4(g_dcc, g_dop, g_dr, g_dg);       // rows: dcc, dr, dop, dg
+                const float rc = wave_sum_hi(g_db);
                 float* dst = s_acc[j];
-                atomicAdd(dst + 0, g_dmx); atomicAdd(dst + 1, g_dmy);
-                atomicAdd(dst + 2, g_dca); atomicAdd(dst + 3, g_dcb); atomicAdd(dst + 4, g_dcc);
-                atomicAdd(dst + 5, g_dop);
-                atomicAdd(dst + 6, g_dr); atomicAdd(dst + 7, g_dg); atomicAdd(dst + 8, g_db);
-                s_touched[j] = 1;
+                if (row_leader) { atomicAdd(dst + col_a, ra); atomicAdd(dst + col_b, rb); }
+                if (l == 63) { atomicAdd(dst + 8, rc); s_touched[j] = 1; }
             }
         }
         __syncthreads();

@@ -60,6 +60,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.binning_capacity = capacity
+        # leaf inputs whose .grad already exists can be accumulated into in place by the backward kernel
+        ctx.leaf_inputs = dict(means3D=means3D, means2D=means2D, sh=sh, colors=colors_precomp, opacity=opacities,
+                               scales=scales, rotations=rotations, cov3D=cov3Ds_precomp) \
+            if config.fused_grad_accumulation() else None
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         return color, radii, depth
 
@@ -72,10 +76,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, grad_depth, sh, rs.sh_degree,
                 rs.campos, geom, ctx.num_rendered, binning, img, rs.debug)
+        accumulate_into = None
+        if ctx.leaf_inputs is not None:
+            accumulate_into = {}
+            for name, t in ctx.leaf_inputs.items():
+                g = t.grad if (t.is_leaf and t.requires_grad and t.numel() != 0) else None
+                if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == means3D.device:
+                    accumulate_into[name] = g
         try:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
-                *args, binning_capacity=ctx.binning_capacity)
+                *args, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into)
         except Exception:
             if rs.debug:
                 _snapshot(args, "snapshot_bw.dump")

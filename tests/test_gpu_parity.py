@@ -206,3 +206,39 @@ def test_async_mode_matches_exact(hip_device):
                                  cloud["shs"].to(dev), 3, camd.camera_center, False, False, binning_capacity=100)
     with pytest.raises(RuntimeError, match="capacity"):
         _C.check(out[4])
+
+
+def test_fused_grad_accumulation_equals_autograd(hip_device):
+    """In-kernel `grad += view gradient` (leaf .grad preallocated) == autograd's dense accumulate, over 3 views."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import config
+    cloud = synthetic.make_cloud(15_000, "band", 9)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(256, 144, n_views=6)[:3]]
+    g = synthetic.upstream_grad(144, 256).to(hip_device)
+    bg = torch.zeros(3, device=hip_device)
+
+    def run(fused):
+        leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
+        m2d = torch.zeros(15_000, 3, device=hip_device, requires_grad=True)
+        if fused:
+            for t in list(leaf.values()) + [m2d]:
+                t.grad = torch.zeros_like(t)
+        config.set_fused_grad_accumulation(fused)
+        try:
+            for c in cams:
+                tfx, tfy = hp.tan_fov(c)
+                rs = GaussianRasterizationSettings(144, 256, tfx, tfy, bg, 1.0, c.world_view_transform,
+                                                   c.full_proj_transform, 3, c.camera_center, False, False)
+                col, radii, dep = GaussianRasterizer(rs)(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                                         shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+                col.backward(g)
+        finally:
+            config.set_fused_grad_accumulation(False)
+        out = {k: v.grad.cpu().numpy() for k, v in leaf.items()}
+        out["means2D"] = m2d.grad.cpu().numpy()
+        return out
+
+    a, b = run(False), run(True)
+    for k in a:
+        scale = np.abs(a[k]).max()
+        assert scale > 0 and np.abs(a[k] - b[k]).max() <= 2e-5 * scale, k   # float atomics reorder sums run to run
