@@ -186,47 +186,47 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
 
-                float g_dmx = 0.f, g_dmy = 0.f, g_dca = 0.f, g_dcb = 0.f, g_dcc = 0.f, g_dop = 0.f;
-                float g_dr = 0.f, g_dg = 0.f, g_db = 0.f;
+                // per-lane scalars from which all nine terms follow; zero for lanes that do not contribute
+                float sG = 0.f;        // dL/dG * G
+                float dchan = 0.f;     // alpha * T  (dL/dcolour weight)
+                float g_dop = 0.f;     // G * dL/dalpha
                 bool contrib = false;
                 if (pos < last_contributor && power <= 0.0f) {
-                    const float G = expf(power);
+                    const float G = __expf(power);
                     const float alpha = fminf(0.99f, b.z * G);
                     if (alpha >= 1.0f / 255.0f) {
                         contrib = true;
                         const float4 c = s_q2[j];
-                        T = T / (1.f - alpha);
-                        const float dchannel_dcolor = alpha * T;
+                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);   // T/(1-a), -T_final/(1-a) share one v_rcp
+                        T = T * rinv;
+                        dchan = alpha * T;
                         float dL_dalpha = 0.f;
                         acr = last_alpha * lcr + (1.f - last_alpha) * acr; lcr = c.x;
-                        dL_dalpha += (c.x - acr) * dLr; g_dr = dchannel_dcolor * dLr;
+                        dL_dalpha += (c.x - acr) * dLr;
                         acg = last_alpha * lcg + (1.f - last_alpha) * acg; lcg = c.y;
-                        dL_dalpha += (c.y - acg) * dLg; g_dg = dchannel_dcolor * dLg;
+                        dL_dalpha += (c.y - acg) * dLg;
                         acb = last_alpha * lcb + (1.f - last_alpha) * acb; lcb = c.z;
-                        dL_dalpha += (c.z - acb) * dLb; g_db = dchannel_dcolor * dLb;
+                        dL_dalpha += (c.z - acb) * dLb;
                         dL_dalpha *= T;
                         last_alpha = alpha;
-                        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-
-                        const float dL_dG = b.z * dL_dalpha;
-                        const float gdx = G * dx, gdy = G * dy;
-                        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                        const float dG_ddely = -gdy * b.x - gdx * a.w;
-                        g_dmx = dL_dG * dG_ddelx * ddelx_dx;
-                        g_dmy = dL_dG * dG_ddely * ddely_dy;
-                        g_dca = -0.5f * gdx * dx * dL_dG;
-                        g_dcb = -0.5f * gdx * dy * dL_dG;
-                        g_dcc = -0.5f * gdy * dy * dL_dG;
+                        dL_dalpha -= T_final * rinv * bg_dot;
                         g_dop = G * dL_dalpha;
+                        sG = b.z * g_dop;                                   // (o * dL/dalpha) * G
                     }
                 }
                 if (__ballot(contrib) == 0) continue;
+                // all lanes (zeros where not contributing): the nine terms of backward.cu:537-583
+                const float sdx = sG * dx, sdy = sG * dy;
+                const float g_dmx = (-sdx * a.z - sdy * a.w) * ddelx_dx;
+                const float g_dmy = (-sdy * b.x - sdx * a.w) * ddely_dy;
+                const float g_dca = -0.5f * sdx * dx, g_dcb = -0.5f * sdx * dy, g_dcc = -0.5f * sdy * dy;
+                const float g_dr = dchan * dLr, g_dg = dchan * dLg, g_db = dchan * dLb;
                 const float ra = reduce4(g_dmx, g_dmy, g_dca, g_dcb);     // rows: dmx, dca, dmy, dcb
                 const float rb = reduce4(g_dcc, g_dop, g_dr, g_dg);       // rows: dcc, dr, dop, dg
-                const float rc = wave_sum_hi(g_db);
+                const float rc = row_sum(g_db);                           // every row: its partial of db
                 float* dst = s_acc[j];
-                if (row_leader) { atomicAdd(dst + col_a, ra); atomicAdd(dst + col_b, rb); }
-                if (l == 63) { atomicAdd(dst + 8, rc); s_touched[j] = 1; }
+                if (row_leader) { atomicAdd(dst + col_a, ra); atomicAdd(dst + col_b, rb); atomicAdd(dst + 8, rc); }
+                if (l == 0) s_touched[j] = 1;
             }
         }
         __syncthreads();

@@ -104,7 +104,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float dx = a.x - pxf, dy = a.y - pyf;
                 const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
                 if (!done && power <= 0.0f) {
-                    const float alpha = fminf(0.99f, b.z * expf(power));
+                    const float alpha = fminf(0.99f, b.z * __expf(power));
                     if (alpha >= 1.0f / 255.0f) {
                         const float test_T = T * (1.0f - alpha);
                         if (test_T < 0.0001f) {
