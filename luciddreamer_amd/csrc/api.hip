@@ -130,6 +130,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     uint2* scan_sums = reinterpret_cast<uint2*>(geom + GL.scan_sums);
     uint32_t* ghist = reinterpret_cast<uint32_t*>(geom + GL.hist);
     uint32_t* tiles_ref = reinterpret_cast<uint32_t*>(geom + GL.tiles_ref);
+    uint32_t* goff = reinterpret_cast<uint32_t*>(geom + GL.goff);
     float* final_T = reinterpret_cast<float*>(img + IL.final_T);
     uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + IL.n_contrib);
     uint2* ranges = reinterpret_cast<uint2*>(img + IL.ranges);
@@ -149,6 +150,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     int num_rendered = 0;
     uint32_t* point_list = nullptr;
     uint32_t* inst_keys_sorted = nullptr;
+    uint32_t* inst_gid = nullptr;
     // which ping-pong half ends up holding the tile-sorted list: a pure function of the tile count
     const int tile_bits = bits_for((uint32_t)(num_tiles - 1));
     const int tile_passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
@@ -196,6 +198,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
         uint32_t* bval_a = reinterpret_cast<uint32_t*>(bin + BL.val_a);
         uint32_t* bval_b = reinterpret_cast<uint32_t*>(bin + BL.val_b);
         uint32_t* bhist = reinterpret_cast<uint32_t*>(bin + BL.hist);
+        inst_gid = reinterpret_cast<uint32_t*>(bin + BL.inst_gid);
 
         // emit into the half from which `tile_passes` ping-pong passes end in (key_a, val_a)
         uint32_t* ekey = (tile_passes & 1) ? bkey_b : bkey_a;
@@ -204,12 +207,12 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
         uint32_t* oval = (tile_passes & 1) ? bval_a : bval_b;
         if (R_bound > 0) {
             { ProfScope ps(ST_EMIT, s);
-            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, ekey, eval, s); }
+            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, (uint32_t)R_bound, ekey, inst_gid, goff, s); }
             LR_DEBUG_SYNC(debug, s, "emit");
             // stable partition by tile id: with the depth order of emission this is the reference's
             // (tile | depth) order (rasterizer_impl.cu:301-309)
             { ProfScope ps(ST_TILE_SORT, s);
-            radix_sort_pairs(ekey, okey, eval, oval, /*iota*/ false, &hdr->num_sorted, R_bound, tile_bits,
+            radix_sort_pairs(ekey, okey, eval, oval, /*iota: the values are emission indices*/ true, &hdr->num_sorted, R_bound, tile_bits,
                              bhist, &inst_keys_sorted, &point_list, s); }
             LR_DEBUG_SYNC(debug, s, "tile sort");
         } else {
@@ -226,7 +229,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
 
     // K6: blend
     { ProfScope ps(ST_RENDER_FWD, s);
-    launch_render_fwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, out_color,
+    launch_render_fwd(width, height, gx, gy, ranges, point_list, inst_gid, rec, background, final_T, n_contrib, out_color,
                       out_depth, s); }
     LR_DEBUG_SYNC(debug, s, "render");
     LR_HIP_CHECK(hipGetLastError());
@@ -264,7 +267,9 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     const ImgLayout IL = img_layout(width, height);
     const GaussRec* rec = reinterpret_cast<const GaussRec*>(geom_buffer + GL.rec);
     const uint8_t* clamped = reinterpret_cast<const uint8_t*>(geom_buffer + GL.clamped);
-    GradRec* grad = reinterpret_cast<GradRec*>(geom_buffer + GL.grad);
+    const uint32_t* tiles_touched = reinterpret_cast<const uint32_t*>(geom_buffer + GL.tiles_touched);
+    const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + GL.goff);
+    const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(geom_buffer + GL.header);
     const float* final_T = reinterpret_cast<const float*>(image_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + IL.n_contrib);
     const uint2* ranges = reinterpret_cast<const uint2*>(image_buffer + IL.ranges);
@@ -283,10 +288,9 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     vp.scale_modifier = scale_modifier;
     vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
 
-    { ProfScope ps(ST_GRAD_ZERO, s);
-    LR_HIP_CHECK(hipMemsetAsync(grad, 0, (size_t)P * sizeof(GradRec), s)); }
     { ProfScope ps(ST_RENDER_BWD, s);
-    launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix, grad, s); }
+    launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix,
+                      binning_buffer, hdr, s); }
     LR_DEBUG_SYNC(debug, s, "render backward");
     {   // tensors in write mode are zero-filled here (one launch); accumulate-mode tensors are left alone
         ProfScope ps(ST_OUT_ZERO, s);
@@ -299,7 +303,8 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
         launch_zero_outputs(zp, zn, zc, s);
     }
     { ProfScope ps(ST_GAUSS_BWD, s);
-    launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, grad,
+    launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, tiles_touched, goff,
+                     binning_buffer, hdr,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                      dL_drot, accumulate_mask, s); }
     LR_DEBUG_SYNC(debug, s, "preprocess backward");

@@ -279,14 +279,15 @@ __device__ __forceinline__ void tile_rect_dev(float px, float py, int radius, in
 __global__ void __launch_bounds__(256)
 k_emit(int P, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
        const uint32_t* __restrict__ tiles_touched, const GaussRec* __restrict__ rec,
-       const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
-       uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals)
+       const int* __restrict__ radii, GeomHeader* __restrict__ hdr, uint32_t bin_bound,
+       uint32_t* __restrict__ inst_keys, uint32_t* __restrict__ inst_vals, uint32_t* __restrict__ goff)
 {
     constexpr uint32_t SMALL = 6;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const uint64_t lt = lanemask_lt();
     const uint32_t cap = hdr->capacity != 0 ? hdr->capacity : 0xFFFFFFFFu;
+    if (k == 0) hdr->bin_bound = bin_bound;
     uint32_t idx = 0, tt = 0, off = 0, area = 0;
     int minx = 0, miny = 0, maxx = 0, maxy = 0;
     float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, qmax = 0.f, r_c = 0.f, r_a = 0.f;
@@ -295,6 +296,7 @@ k_emit(int P, int gx, int gy, const uint32_t* __restrict__ order, const uint32_t
         tt = tiles_touched[idx];                   // instances to emit (after exact tile culling, preprocess.hip)
         if (tt != 0) {
             off = offsets[k];
+            goff[idx] = off;                           // where this Gaussian's instance slots start (emission order)
             const float4* g = reinterpret_cast<const float4*>(rec + idx);
             const float4 q0 = g[0];
             const float4 q1 = g[1];
@@ -407,10 +409,10 @@ void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touch
 
 void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* offsets,
                  const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
-                 uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t s)
+                 uint32_t bin_bound, uint32_t* inst_keys, uint32_t* inst_gid, uint32_t* goff, hipStream_t s)
 {
     hipLaunchKernelGGL(k_emit, dim3((P + 255) / 256), dim3(256), 0, s, P, gx, gy, order, offsets, tiles_touched,
-                       rec, radii, hdr, inst_keys, inst_vals);
+                       rec, radii, hdr, bin_bound, inst_keys, inst_gid, goff);
 }
 
 void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long n_bound, int num_tiles,

@@ -39,7 +39,7 @@ struct GeomHeader {
     uint32_t P;
     uint32_t num_sorted;            // min(num_instances, capacity): length of the instance list actually built
     uint32_t num_instances;         // tile instances after exact tile culling (what is emitted and sorted)
-    uint32_t unused0;
+    uint32_t bin_bound;             // instance count the binning buffer was laid out for (R or capacity)
     uint32_t reserved[56];
 };
 static_assert(sizeof(GeomHeader) == 256, "GeomHeader must be 256 bytes");
@@ -66,7 +66,7 @@ inline SortPlan sort_plan(long long n_bound) {
     p.nblocks = (int)((tiles + tiles_per_block - 1) / tiles_per_block);
     return p;
 }
-inline size_t sort_hist_bytes(long long n_bound) {
+__host__ __device__ inline size_t sort_hist_bytes(long long n_bound) {
     return align_up((size_t)SORT_MAX_BLOCKS * RADIX_SIZE * 4 + RADIX_SIZE * 4);
 }
 
@@ -77,7 +77,7 @@ constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, key_a, key_b, val_a, val_b, offsets, scan_sums, hist, grad, tiles_ref, total;
+    size_t header, rec, clamped, tiles_touched, key_a, key_b, val_a, val_b, offsets, scan_sums, hist, goff, tiles_ref, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -92,7 +92,7 @@ inline GeomLayout geom_layout(int P) {
     L.offsets = o;       o += align_up(Pz * 4);
     L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
     L.hist = o;          o += sort_hist_bytes((long long)Pz);
-    L.grad = o;          o += align_up(Pz * sizeof(GradRec));
+    L.goff = o;          o += align_up(Pz * 4);
     L.tiles_ref = o;     o += align_up(Pz * 4);
     L.total = o;
     return L;
@@ -107,16 +107,21 @@ inline ImgLayout img_layout(int W, int H) {
     L.total = o;
     return L;
 }
-struct BinLayout { size_t key_a, key_b, val_a, val_b, hist, total; };
-inline BinLayout bin_layout(long long R) {
+struct BinLayout { size_t key_a, key_b, val_a, val_b, hist, inst_gid, inst_grad, total; };
+__host__ __device__ inline BinLayout bin_layout(long long R) {
     // val_a sits at offset 0 and always receives the final tile-sorted list (the emit target is chosen by
-    // the parity of the number of sort passes), so the backward finds it without knowing R.
+    // the parity of the number of sort passes).  The list holds EMISSION indices e; inst_gid[e] is the
+    // Gaussian and inst_grad[e] the slot the blend backward writes that instance's nine partial sums to
+    // (one plain 48-byte store per tile instance instead of nine global atomics).  The backward resolves
+    // the R-dependent offsets on the device from GeomHeader::bin_bound.
     BinLayout L; size_t o = 0; size_t Rz = R > 0 ? (size_t)R : 1;
     L.val_a = o; o += align_up(Rz * 4);
     L.val_b = o; o += align_up(Rz * 4);
     L.key_a = o; o += align_up(Rz * 4);
     L.key_b = o; o += align_up(Rz * 4);
     L.hist = o;  o += sort_hist_bytes((long long)Rz);
+    L.inst_gid = o;  o += align_up(Rz * 4);
+    L.inst_grad = o; o += align_up(Rz * sizeof(GradRec));
     L.total = o;
     return L;
 }
@@ -199,19 +204,21 @@ void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touch
                        uint32_t* offsets, uint2* block_sums, GeomHeader* hdr, hipStream_t s);
 void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* offsets,
                  const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
-                 uint32_t* inst_keys, uint32_t* inst_vals, hipStream_t s);
+                 uint32_t bin_bound, uint32_t* inst_keys, uint32_t* inst_gid, uint32_t* goff, hipStream_t s);
 void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long n_bound, int num_tiles,
                    uint2* ranges, hipStream_t s);
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
-                       const GaussRec* rec, const float* bg, float* final_T,
+                       const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s);
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
-                       const uint32_t* n_contrib, const float* dL_dpix, GradRec* grad, hipStream_t s);
+                       const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
+                       hipStream_t s);
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const int* radii, const uint8_t* clamped, const GradRec* grad,
+                      const int* radii, const uint8_t* clamped, const uint32_t* tiles_touched,
+                      const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, hipStream_t s);

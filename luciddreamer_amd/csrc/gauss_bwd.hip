@@ -124,7 +124,7 @@ __device__ __forceinline__ void
 gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
             const float* __restrict__ cov3D_precomp,
-            const uint8_t* __restrict__ clamped, const GradRec* __restrict__ grad,
+            const uint8_t* __restrict__ clamped, const float4 g0, const float4 g1, const float4 g2,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
@@ -144,8 +144,6 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
     for (int k = 0; k < 48; k++) dsh[k] = 0.f;
 
     {
-        const float4* gp = reinterpret_cast<const float4*>(grad + i);
-        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
         const float gmx = g0.x, gmy = g0.y;                 // dL/dmean2D
         const float gca = g0.z, gcb = g0.w, gcc = g1.x;     // dL/dconic (x, y, w)
         o_op = g1.y;
@@ -349,16 +347,26 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
 // order (and with it coalescing of the row reads/writes) is preserved, and no global atomics are needed.
 constexpr int GB_CHUNK = 1024;
 
+__device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
 __global__ void __launch_bounds__(256)
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
             const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
-            const uint8_t* __restrict__ clamped, const GradRec* __restrict__ grad,
+            const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
+            const uint32_t* __restrict__ goff, const char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
             uint32_t accum_mask)
 {
+    constexpr uint32_t SERIAL_MAX = 24;      // instances summed by the owning lane; more -> whole wave helps
     __shared__ uint32_t s_list[GB_CHUNK];
     __shared__ uint32_t s_count;
     if (threadIdx.x == 0) s_count = 0;
@@ -368,7 +376,8 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
 #pragma unroll
     for (int r = 0; r < GB_CHUNK / 256; r++) {
         const int idx = base + r * 256 + (int)threadIdx.x;
-        const bool vis = idx < vp.P && radii[idx] > 0;
+        // a visible Gaussian whose tiles were all culled has an all-zero gradient: nothing to do for it
+        const bool vis = idx < vp.P && radii[idx] > 0 && tiles_touched[idx] != 0;
         const uint64_t m = __ballot(vis);
         uint32_t pos = 0;
         if (lane == 0 && m != 0) pos = atomicAdd(&s_count, (uint32_t)__popcll(m));
@@ -377,10 +386,48 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
     }
     __syncthreads();
     const uint32_t n = s_count;
-    for (uint32_t t = threadIdx.x; t < n; t += 256)
-        gauss_backward_one((int)s_list[t], vp, means3D, scales, rotations, shs, cov3D_precomp, clamped, grad,
-                           dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
-                           dL_drot, accum_mask);
+    if (n == 0) return;
+    // per-instance partial sums written by k_render_bwd (48-byte slots, contiguous per Gaussian in emission
+    // order); slots at or beyond num_sorted were never built (async-mode overflow) and are ignored
+    const float4* __restrict__ inst_grad =
+        reinterpret_cast<const float4*>(bin_base + bin_layout((long long)hdr->bin_bound).inst_grad);
+    const uint32_t n_slots = hdr->num_sorted;
+
+    for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+        const uint32_t t = t0 + threadIdx.x;
+        const bool live = t < n;
+        const int idx = live ? (int)s_list[t] : 0;
+        const uint32_t tt = live ? tiles_touched[idx] : 0u;
+        const uint32_t off = live ? goff[idx] : 0u;
+        float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
+        if (tt <= SERIAL_MAX) {
+            for (uint32_t j = 0; j < tt; j++) {
+                if (off + j >= n_slots) break;
+                const float4* slot = inst_grad + 3 * (size_t)(off + j);
+                add4(g0, slot[0]); add4(g1, slot[1]); add4(g2, slot[2]);
+            }
+        }
+        uint64_t big = __ballot(tt > SERIAL_MAX);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t b_tt = __shfl(tt, src), b_off = __shfl(off, src);
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0;
+            for (uint32_t j = lane; j < b_tt; j += 64) {
+                if (b_off + j >= n_slots) break;
+                const float4* slot = inst_grad + 3 * (size_t)(b_off + j);
+                add4(p0, slot[0]); add4(p1, slot[1]); add4(p2, slot[2]);
+            }
+            p0.x = wave_sum(p0.x); p0.y = wave_sum(p0.y); p0.z = wave_sum(p0.z); p0.w = wave_sum(p0.w);
+            p1.x = wave_sum(p1.x); p1.y = wave_sum(p1.y); p1.z = wave_sum(p1.z); p1.w = wave_sum(p1.w);
+            p2.x = wave_sum(p2.x);
+            if (lane == src) { g0 = p0; g1 = p1; g2 = p2; }
+        }
+        if (live)
+            gauss_backward_one(idx, vp, means3D, scales, rotations, shs, cov3D_precomp, clamped, g0, g1, g2,
+                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+                               dL_drot, accum_mask);
+    }
 }
 
 struct ZeroSegs { float4* p[9]; unsigned long long n4[9]; unsigned long long off[10]; int count; };
@@ -433,7 +480,8 @@ void launch_zero_outputs(float* const* ptrs, const unsigned long long* nfloats, 
 
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const int* radii, const uint8_t* clamped, const GradRec* grad,
+                      const int* radii, const uint8_t* clamped, const uint32_t* tiles_touched,
+                      const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, hipStream_t s)
@@ -441,7 +489,7 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
     (void)colors_precomp;
     if (vp.P <= 0) return;
     hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + GB_CHUNK - 1) / GB_CHUNK), dim3(256), 0, s, vp, means3D, scales, rotations, shs,
-                       cov3D_precomp, radii, clamped, grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+                       cov3D_precomp, radii, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                        dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
 }
 

@@ -15,8 +15,9 @@
 //                  halves TWO terms at once) + 4 DPP steps inside the 16-lane rows = 20 instructions
 //                  (a per-term DPP tree costs 48 + hazards nops), 9th term by DPP;
 //                  -> 3 LDS float-add instructions per wave (4+4+1 lanes) into a per-batch accumulator
-//                  -> one global atomic per term per Gaussian per TILE, issued by 256 threads in
-//                     parallel into one 48-byte GradRec instead of four arrays.
+//                  -> ONE plain 48-byte store per tile instance into that instance's own slot
+//                     (inst_grad[emission index]); the slots of a Gaussian are contiguous and are summed,
+//                     in a fixed order, by k_gauss_bwd.  No global atomics at all, nothing to pre-zero.
 #include "common.h"
 
 namespace lr {
@@ -92,15 +93,14 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-             GradRec* __restrict__ grad)
+             char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, conic a, conic b
     __shared__ float4 s_q1[BATCH];      // conic c, qmax, opacity, -
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
-    __shared__ uint32_t s_id[BATCH];
+    __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
     __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (4 waves add into it)
-    __shared__ uint32_t s_touched[BATCH];
     __shared__ uint32_t s_wlast[4];
 
     const int tile = swizzled_tile(num_tiles);
@@ -117,6 +117,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    if (total == 0) return;
+    // R-dependent parts of the binning buffer, resolved on the device (the host does not know R here)
+    const BinLayout BL = bin_layout((long long)hdr->bin_bound);
+    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
+    float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
 
     const float T_final = inside ? final_Ts[pix] : 0.f;
     float T = T_final;
@@ -146,21 +151,27 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         const int cnt = min(BATCH, total - base);
         const int pos_hi = total - 1 - base;             // position of staged element 0
         const int pos_lo = pos_hi - (cnt - 1);
-        if ((uint32_t)pos_lo >= tile_last) continue;     // whole batch lies behind every last contributor
+        if ((uint32_t)pos_lo >= tile_last) {             // whole batch lies behind every last contributor:
+            if (tid < cnt) {                             // its instance slots still have to read as zero
+                float4* slot = inst_grad + 3 * (size_t)point_list[range.x + (pos_hi - tid)];
+                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f); slot[1] = slot[0]; slot[2] = slot[0];
+            }
+            continue;
+        }
         __syncthreads();                                  // previous batch fully consumed / flushed
         if (tid < cnt) {
-            const uint32_t id = point_list[range.x + (pos_hi - tid)];
+            const uint32_t e = point_list[range.x + (pos_hi - tid)];     // emission index of this instance
+            const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[tid] = a;
             s_q1[tid] = make_float4(b.x, c.z, b.y, 0.f);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
-            s_id[tid] = id;
+            s_id[tid] = e;
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) s_acc[tid][k] = 0.f;
-        s_touched[tid] = 0;
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
@@ -226,14 +237,17 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float rc = row_sum(g_db);                           // every row: its partial of db
                 float* dst = s_acc[j];
                 if (row_leader) { atomicAdd(dst + col_a, ra); atomicAdd(dst + col_b, rb); atomicAdd(dst + 8, rc); }
-                if (l == 0) s_touched[j] = 1;
             }
         }
         __syncthreads();
-        if (tid < cnt && s_touched[tid]) {
-            float* dst = reinterpret_cast<float*>(grad + s_id[tid]);
-#pragma unroll
-            for (int k = 0; k < 9; k++) atomicAdd(dst + k, s_acc[tid][k]);
+        if (tid < cnt) {
+            // every instance owns one 48-byte slot: plain stores, no atomics, and the per-Gaussian sum in
+            // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed)
+            const float* a9 = s_acc[tid];
+            float4* slot = inst_grad + 3 * (size_t)s_id[tid];
+            slot[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
+            slot[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+            slot[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
         }
     }
 }
@@ -242,13 +256,14 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
-                       const uint32_t* n_contrib, const float* dL_dpix, GradRec* grad, hipStream_t s)
+                       const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
+                       hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int grid = ((num_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
-                       final_T, n_contrib, dL_dpix, grad);
+                       final_T, n_contrib, dL_dpix, bin_base, hdr);
 }
 
 }  // namespace lr

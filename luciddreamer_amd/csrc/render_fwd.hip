@@ -34,7 +34,8 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
 
 __global__ void __launch_bounds__(256)
 k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
+             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
+             const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ out_color, float* __restrict__ out_depth)
 {
@@ -70,7 +71,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         if (s_wdone[0] + s_wdone[1] + s_wdone[2] + s_wdone[3] == 4) break;
         const int cnt = min(BATCH, total - base);
         if (tid < cnt) {
-            const uint32_t id = point_list[range.x + base + tid];
+            const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[tid] = a;
@@ -140,14 +141,14 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 }  // namespace
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
-                       const GaussRec* rec, const float* bg, float* final_T,
+                       const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int grid = ((num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
-                       final_T, n_contrib, out_color, out_depth);
+    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, inst_gid,
+                       rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 
 }  // namespace lr

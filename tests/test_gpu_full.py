@@ -35,7 +35,7 @@ def _unpack(out, P, W, H):
     """Mirror of csrc/common.h geom/img/bin layouts (opaque to users; the test knows them)."""
     num_rendered, color, depth, radii, geom, binning, img = out
     g = geom.cpu().numpy()
-    hdr = g[:32].view(np.uint32)          # num_rendered, overflow, trap, capacity, P, num_sorted, num_instances, num_visible
+    hdr = g[:32].view(np.uint32)          # num_rendered, overflow, trap, capacity, P, num_sorted, num_instances, bin_bound
     rec = g[256:256 + 48 * P].view(np.float32).reshape(P, 12)
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     im = img.cpu().numpy()
@@ -43,7 +43,12 @@ def _unpack(out, P, W, H):
     n_contrib = im[_align(4 * N):_align(4 * N) + 4 * N].view(np.uint32).reshape(H, W)
     ranges = im[2 * _align(4 * N):2 * _align(4 * N) + 8 * T].view(np.uint32).reshape(T, 2)
     n_inst = int(hdr[5])
-    point_list = binning.cpu().numpy()[:4 * n_inst].view(np.uint32)      # the final list is always at offset 0
+    b = binning.cpu().numpy()
+    emission = b[:4 * n_inst].view(np.uint32)               # final tile-sorted list (emission indices), offset 0
+    seg = _align(4 * max(int(hdr[7]), 1))                   # hdr[7] = bin_bound the layout was computed for
+    gid_off = 4 * seg + _align(1024 * 256 * 4 + 256 * 4)    # val_a, val_b, key_a, key_b, histogram scratch
+    inst_gid = b[gid_off:gid_off + 4 * max(int(hdr[7]), 1)].view(np.uint32)
+    point_list = inst_gid[emission]                         # Gaussian index of every list entry
     return dict(rec=rec, final_T=final_T, n_contrib=n_contrib, ranges=ranges, point_list=point_list, hdr=hdr)
 
 
