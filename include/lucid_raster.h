@@ -122,6 +122,8 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
  *   dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (slots x,y,w; may be NULL), dL_dopacity [P],
  *   dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL iff shs NULL),
  *   dL_dscale [P,3], dL_drot [P,4] (written as zeros when cov3D_precomp is used).
+ * Intermediate outputs the caller does not need may be NULL: dL_dconic always; dL_dcolor unless
+ * colors_precomp is given; dL_dcov3D unless cov3D_precomp is given; dL_dscale/dL_drot unless scales is given.
  * Returns 0 or a negative LR_ERR_*.
  */
 int lr_backward(int P, int D, int M, int R,

@@ -115,10 +115,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color,
                                  dL_dout_depth, sh, degree, campos, geomBuffer, R, binningBuffer, imageBuffer,
-                                 debug, *, binning_capacity=0, accumulate_into=None):
+                                 debug, *, binning_capacity=0, accumulate_into=None, skip_unused=False):
     """accumulate_into (optional): {name: tensor} with names among ACC_BITS; the gradient of that input is
     ADDED in place into the given contiguous float32 tensor (rows of culled Gaussians untouched) and the
-    corresponding slot of the returned tuple is None."""
+    corresponding slot of the returned tuple is None.
+    skip_unused: do not materialise gradients of inputs that are absent (dL_dcolors when SHs are used, dL_dcov3D /
+    dL_dscales / dL_drotations for the representation not in use); their slots are None.  The reference always
+    returns all eight tensors, so the default keeps that."""
     _require_device(means3D, "means3D")
     dev = means3D.device
     L = _lib.lib()
@@ -133,7 +136,18 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     shapes = {"means3D": (P, 3), "means2D": (P, 3), "colors": (P, NUM_CHANNELS), "opacity": (P, 1), "cov3D": (P, 6),
               "sh": (P, M, 3), "scales": (P, 3), "rotations": (P, 4)}
     outs = {}
+    unused = set()
+    if skip_unused:
+        if colors is None or colors.numel() == 0:
+            unused.add("colors")
+        if cov3D_precomp is None or cov3D_precomp.numel() == 0:
+            unused.add("cov3D")
+        if scales is None or scales.numel() == 0:
+            unused.update(("scales", "rotations"))
     for name, shape in shapes.items():
+        if name in unused:
+            outs[name] = None
+            continue
         t = acc.get(name)
         if t is not None:
             n = 1
@@ -167,9 +181,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                                _ptr(view), _ptr(proj), _ptr(cam), float(tan_fovx), float(tan_fovy),
                                radii_c.data_ptr(), geomBuffer.data_ptr(), binningBuffer.data_ptr(),
                                imageBuffer.data_ptr(), _ptr(g_color), _ptr(g_depth),
-                               dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), dL_dcolors.data_ptr(),
-                               dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), _ptr(dL_dsh) if M else None,
-                               dL_dscales.data_ptr(), dL_drotations.data_ptr(), int(bool(debug)),
+                               dL_dmeans2D.data_ptr(), None, dL_dopacity.data_ptr(), _ptr(dL_dcolors),
+                               dL_dmeans3D.data_ptr(), _ptr(dL_dcov3D), _ptr(dL_dsh) if M else None,
+                               _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)),
                                int(binning_capacity), mask, _stream(dev))
         if rc < 0:
             _lib.raise_for(rc, "rasterize_gaussians_backward")

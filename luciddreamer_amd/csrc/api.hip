@@ -40,9 +40,9 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 // ---- optional per-stage HIP-event timing (used by bench.py for the roofline figures) ----------
-enum Stage { ST_PREPROCESS = 0, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_RENDER_FWD,
+enum Stage { ST_PREPROCESS = 0, ST_COMPACT, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_RENDER_FWD,
              ST_GRAD_ZERO, ST_RENDER_BWD, ST_OUT_ZERO, ST_GAUSS_BWD, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = { "preprocess", "depth_sort", "scan", "emit", "tile_sort", "ranges",
+const char* const kStageNames[ST_COUNT] = { "preprocess", "compact", "depth_sort", "scan", "emit", "tile_sort", "ranges",
                                             "render_fwd", "grad_zero", "render_bwd", "out_zero", "gauss_bwd" };
 struct ProfRec { int stage; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -163,10 +163,14 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
                           (uint32_t)binning_capacity, s); }
         LR_DEBUG_SYNC(debug, s, "preprocess");
 
-        // depth order of the Gaussians (stable, value = index); culled ones (key 0xFFFFFFFF) go last
+        // compact the Gaussians that emit anything (index order kept), then depth-sort only those
+        // (stable, value = Gaussian index)
+        { ProfScope ps(ST_COMPACT, s);
+        launch_compact(P, tiles_touched, tiles_ref, gkey_a, scan_sums, gkey_b, gval_b, hdr, s); }
+        LR_DEBUG_SYNC(debug, s, "compact");
         uint32_t *sorted_depth_keys, *order;
         { ProfScope ps(ST_DEPTH_SORT, s);
-        radix_sort_pairs(gkey_a, gkey_b, gval_a, gval_b, /*iota*/ true, &hdr->P, P, 32, ghist, &sorted_depth_keys,
+        radix_sort_pairs(gkey_b, gkey_a, gval_b, gval_a, /*iota*/ false, &hdr->num_compact, P, 32, ghist, &sorted_depth_keys,
                          &order, s); }
         (void)sorted_depth_keys;
         LR_DEBUG_SYNC(debug, s, "depth sort");
@@ -258,8 +262,11 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (P <= 0) return 0;
     if (!geom_buffer || !binning_buffer || !image_buffer) return fail(LR_ERR_INVALID_ARG, "scratch buffers are required");
-    if (!dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
-        return fail(LR_ERR_INVALID_ARG, "gradient outputs are required");
+    if (!dL_dpix || !dL_dmean2D || !dL_dopacity || !dL_dmean3D)
+        return fail(LR_ERR_INVALID_ARG, "gradient outputs dL_dmean2D/dL_dopacity/dL_dmean3D are required");
+    if (colors_precomp != nullptr && !dL_dcolor) return fail(LR_ERR_INVALID_ARG, "dL_dcolor is required with colors_precomp");
+    if (cov3D_precomp != nullptr && !dL_dcov3D) return fail(LR_ERR_INVALID_ARG, "dL_dcov3D is required with cov3D_precomp");
+    if (scales != nullptr && (!dL_dscale || !dL_drot)) return fail(LR_ERR_INVALID_ARG, "dL_dscale/dL_drot are required with scales");
     if (shs != nullptr && dL_dsh == nullptr) return fail(LR_ERR_INVALID_ARG, "dL_dsh is required when shs is given");
 
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;

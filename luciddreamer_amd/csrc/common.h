@@ -40,7 +40,8 @@ struct GeomHeader {
     uint32_t num_sorted;            // min(num_instances, capacity): length of the instance list actually built
     uint32_t num_instances;         // tile instances after exact tile culling (what is emitted and sorted)
     uint32_t bin_bound;             // instance count the binning buffer was laid out for (R or capacity)
-    uint32_t reserved[56];
+    uint32_t num_compact;           // Gaussians that emit at least one instance (length of the compacted arrays)
+    uint32_t reserved[55];
 };
 static_assert(sizeof(GeomHeader) == 256, "GeomHeader must be 256 bytes");
 
@@ -198,6 +199,10 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
                       const uint32_t* n_dev, long long n_bound, int end_bit, uint32_t* hist,
                       uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
 
+// Order-preserving compaction of the Gaussians with tiles_touched != 0: (ckey, cidx) <- (depth_key, index);
+// count -> hdr->num_compact, sum of tiles_ref over all Gaussians -> hdr->num_rendered.
+void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, const uint32_t* depth_key,
+                    uint2* block_sums, uint32_t* ckey, uint32_t* cidx, GeomHeader* hdr, hipStream_t s);
 // offsets[k] = exclusive prefix of tiles_touched[order[k]], k in depth order; total -> hdr->num_instances
 // (and the overflow flag against hdr->capacity); sum of tiles_ref -> hdr->num_rendered (reference count).
 void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, const uint32_t* tiles_ref,

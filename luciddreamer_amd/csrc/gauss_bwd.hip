@@ -304,14 +304,14 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
     }
     LR_OUT(ACC_OPACITY, dL_dopacity + i, o_op);
 #pragma unroll
-    for (int k = 0; k < 3; k++) LR_OUT(ACC_COLOR, dL_dcolor + 3 * i + k, o_col[k]);
+    for (int k = 0; k < 3; k++) if (dL_dcolor != nullptr) LR_OUT(ACC_COLOR, dL_dcolor + 3 * i + k, o_col[k]);
 #pragma unroll
     for (int k = 0; k < 3; k++) LR_OUT(ACC_MEAN3D, dL_dmean3D + 3 * i + k, o_m3d[k]);
 #pragma unroll
-    for (int k = 0; k < 6; k++) LR_OUT(ACC_COV3D, dL_dcov3D + 6 * i + k, o_cov[k]);
+    for (int k = 0; k < 6; k++) if (dL_dcov3D != nullptr) LR_OUT(ACC_COV3D, dL_dcov3D + 6 * i + k, o_cov[k]);
 #pragma unroll
-    for (int k = 0; k < 3; k++) LR_OUT(ACC_SCALE, dL_dscale + 3 * i + k, o_scale[k]);
-    {
+    for (int k = 0; k < 3; k++) if (dL_dscale != nullptr) LR_OUT(ACC_SCALE, dL_dscale + 3 * i + k, o_scale[k]);
+    if (dL_drot != nullptr) {
         float4* pr = reinterpret_cast<float4*>(dL_drot) + idx;
         float4 v = make_float4(o_rot[0], o_rot[1], o_rot[2], o_rot[3]);
         if ((accum_mask >> ACC_ROT) & 1u) { const float4 o = *pr; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }

@@ -86,7 +86,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         try:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
              grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
-                *args, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into)
+                *args, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into, skip_unused=True)
         except Exception:
             if rs.debug:
                 _snapshot(args, "snapshot_bw.dump")
