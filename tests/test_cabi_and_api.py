@@ -49,8 +49,9 @@ def test_size_queries_are_pure_host_functions(built_lib):
     assert 0 < g1 < g2 and g1 % 256 == 0
     assert L.lr_img_bytes(1920, 1080) >= 1920 * 1080 * 8
     assert L.lr_binning_bytes(10) < L.lr_binning_bytes(10_000_000)
-    # 16 B per tile instance + fixed histogram scratch (reference: ~24 B + sort temp)
-    assert (L.lr_binning_bytes(10_000_000) - L.lr_binning_bytes(0)) // 10_000_000 <= 16
+    # per tile instance: 16 B sort ping-pong + 4 B Gaussian id + 48 B gradient slot (reference: ~24 B + sort temp,
+    # and 9 global atomics per pixel pair instead of the slot)
+    assert (L.lr_binning_bytes(10_000_000) - L.lr_binning_bytes(0)) // 10_000_000 <= 68
 
 
 def test_settings_tuple_matches_reference_fields():
