@@ -24,7 +24,7 @@ namespace lr {
 
 namespace {
 
-constexpr int BATCH = 256;
+constexpr int BATCH = 128;          // staged Gaussians per round = threads per workgroup
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp(float v)
@@ -87,8 +87,16 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
     return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+
 // s_acc column of each term: 0 dmx, 1 dmy, 2 dca, 3 dcb, 4 dcc, 5 dop, 6 dr, 7 dg, 8 db (= GradRec float order)
-__global__ void __launch_bounds__(256)
+//
+// 128 threads = 2 wave64 per 16x16 tile; a wave owns a 16x8 half tile, a lane owns TWO pixels (same row, 8
+// columns apart) and all per-pixel arithmetic is packed FP32 on 2-vectors.  The blend recursion is
+// branch-free: a pixel for which the Gaussian is skipped processes it as a layer with alpha = 0 and G = 0,
+// which leaves T, accum_rec and every gradient term exactly unchanged (T * rcp(1-0) = T; the colour
+// recursion folds the previous contributor in once, then passes it through with weight 1).
+__global__ void __launch_bounds__(BATCH)
 k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -100,19 +108,20 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
-    __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (4 waves add into it)
-    __shared__ uint32_t s_wlast[4];
+    __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (both waves add into it)
+    __shared__ uint32_t s_wlast[2];
 
     const int tile = swizzled_tile(num_tiles);
     if (tile >= num_tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int qx = tx * TILE_X + (w & 1) * 8, qy = ty * TILE_Y + (w >> 1) * 8;
-    const int px = qx + (l & 7), py = qy + (l >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)qx, bx1 = (float)(qx + 7), by0 = (float)qy, by1 = (float)(qy + 7);
-    const size_t pix = (size_t)py * W + px;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y + w * 8;          // this wave's 16x8 box
+    const int pxA = x0 + (l & 7), pxB = pxA + 8, py = y0 + (l >> 3);
+    const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
+    const v2f pxf = { (float)pxA, (float)pxB };
+    const float pyf = (float)py;
+    const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
+    const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
     const size_t N = (size_t)W * H;
 
     const uint2 range = ranges[tile];
@@ -123,28 +132,31 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
 
-    const float T_final = inside ? final_Ts[pix] : 0.f;
-    float T = T_final;
-    const uint32_t last_contributor = inside ? n_contrib[pix] : 0u;
-    const uint32_t wave_last = wave_max_u32(last_contributor);       // nothing at or behind this matters to the wave
-    float dLr = 0.f, dLg = 0.f, dLb = 0.f;
-    if (inside) { dLr = dL_dpix[pix]; dLg = dL_dpix[N + pix]; dLb = dL_dpix[2 * N + pix]; }
-    const float bg_dot = bg[0] * dLr + bg[1] * dLg + bg[2] * dLb;
-    float acr = 0.f, acg = 0.f, acb = 0.f;      // accum_rec
-    float last_alpha = 0.f, lcr = 0.f, lcg = 0.f, lcb = 0.f;
+    const v2f T_final = { insA ? final_Ts[pixA] : 0.f, insB ? final_Ts[pixB] : 0.f };
+    v2f T = T_final;
+    const uint32_t lastA = insA ? n_contrib[pixA] : 0u, lastB = insB ? n_contrib[pixB] : 0u;
+    const uint32_t wave_last = wave_max_u32(max(lastA, lastB));     // nothing at or behind this matters to the wave
+    v2f dLr = { 0.f, 0.f }, dLg = dLr, dLb = dLr;
+    if (insA) { dLr.x = dL_dpix[pixA]; dLg.x = dL_dpix[N + pixA]; dLb.x = dL_dpix[2 * N + pixA]; }
+    if (insB) { dLr.y = dL_dpix[pixB]; dLg.y = dL_dpix[N + pixB]; dLb.y = dL_dpix[2 * N + pixB]; }
+    const v2f bgT = (bg[0] * dLr + bg[1] * dLg + bg[2] * dLb) * T_final;      // T_final * bg . dL/dpixel
+    v2f acr = { 0.f, 0.f }, acg = acr, acb = acr;      // accum_rec
+    v2f last_alpha = acr, lcr = acr, lcg = acr, lcb = acr;
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
 
     // block-uniform: the deepest contributor of any pixel in the tile; batches entirely behind it are skipped
     if (l == 0) s_wlast[w] = wave_last;
     __syncthreads();
-    const uint32_t tile_last = max(max(s_wlast[0], s_wlast[1]), max(s_wlast[2], s_wlast[3]));
+    const uint32_t tile_last = max(s_wlast[0], s_wlast[1]);
 
     // LDS column written by this lane after the reductions: rows of reduce4 hold terms {v0, v2, v1, v3}
     const int row = l >> 4;
     const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // reduce4(dmx, dmy, dca, dcb)
     const int col_b = (row == 0) ? 4 : (row == 1) ? 6 : (row == 2) ? 5 : 7;     // reduce4(dcc, dop, dr, dg)
     const bool row_leader = (l & 15) == 0;
+    int opaque_zero = 0;                         // keeps the compiler's uniform-address atomic rewrite away from
+    asm volatile("" : "+v"(opaque_zero));        // the 4-lane LDS add below (it would expand to a readlane loop)
 
     for (int base = 0; base < total; base += BATCH) {
         // staged element i <-> list position pos = total-1-base-i (back to front)
@@ -175,7 +187,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
-            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the quadrant
+            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the wave's 16x8 box
             bool hit = false;
             {
                 const int j = sb + l;
@@ -194,49 +206,48 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 const float4 a = s_q0[j];
                 const float4 b = s_q1[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-
-                // per-lane scalars from which all nine terms follow; zero for lanes that do not contribute
-                float sG = 0.f;        // dL/dG * G
-                float dchan = 0.f;     // alpha * T  (dL/dcolour weight)
-                float g_dop = 0.f;     // G * dL/dalpha
-                bool contrib = false;
-                if (pos < last_contributor && power <= 0.0f) {
-                    const float G = __expf(power);
-                    const float alpha = fminf(0.99f, b.z * G);
-                    if (alpha >= 1.0f / 255.0f) {
-                        contrib = true;
-                        const float4 c = s_q2[j];
-                        const float rinv = __builtin_amdgcn_rcpf(1.f - alpha);   // T/(1-a), -T_final/(1-a) share one v_rcp
-                        T = T * rinv;
-                        dchan = alpha * T;
-                        float dL_dalpha = 0.f;
-                        acr = last_alpha * lcr + (1.f - last_alpha) * acr; lcr = c.x;
-                        dL_dalpha += (c.x - acr) * dLr;
-                        acg = last_alpha * lcg + (1.f - last_alpha) * acg; lcg = c.y;
-                        dL_dalpha += (c.y - acg) * dLg;
-                        acb = last_alpha * lcb + (1.f - last_alpha) * acb; lcb = c.z;
-                        dL_dalpha += (c.z - acb) * dLb;
-                        dL_dalpha *= T;
-                        last_alpha = alpha;
-                        dL_dalpha -= T_final * rinv * bg_dot;
-                        g_dop = G * dL_dalpha;
-                        sG = b.z * g_dop;                                   // (o * dL/dalpha) * G
-                    }
-                }
-                if (__ballot(contrib) == 0) continue;
-                // all lanes (zeros where not contributing): the nine terms of backward.cu:537-583
-                const float sdx = sG * dx, sdy = sG * dy;
-                const float g_dmx = (-sdx * a.z - sdy * a.w) * ddelx_dx;
-                const float g_dmy = (-sdy * b.x - sdx * a.w) * ddely_dy;
-                const float g_dca = -0.5f * sdx * dx, g_dcb = -0.5f * sdx * dy, g_dcc = -0.5f * sdy * dy;
-                const float g_dr = dchan * dLr, g_dg = dchan * dLg, g_db = dchan * dLb;
-                const float ra = reduce4(g_dmx, g_dmy, g_dca, g_dcb);     // rows: dmx, dca, dmy, dcb
-                const float rb = reduce4(g_dcc, g_dop, g_dr, g_dg);       // rows: dcc, dr, dop, dg
-                const float rc = row_sum(g_db);                           // every row: its partial of db
+                const float4 c = s_q2[j];
+                const v2f dx = a.x - pxf;
+                const float dy = a.y - pyf;
+                const v2f power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const v2f Graw = { __expf(power.x), __expf(power.y) };
+                const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, b.z * Graw);
+                // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0,
+                // alpha < 1/255  ->  skipped; here: processed as a layer with alpha = 0, G = 0
+                const bool vA = pos < lastA && power.x <= 0.0f && araw.x >= 1.0f / 255.0f;
+                const bool vB = pos < lastB && power.y <= 0.0f && araw.y >= 1.0f / 255.0f;
+                if (__ballot(vA || vB) == 0) continue;            // nothing in 128 pixels: state is unchanged
+                const v2f alpha = { vA ? araw.x : 0.f, vB ? araw.y : 0.f };
+                const v2f G = { vA ? Graw.x : 0.f, vB ? Graw.y : 0.f };
+                const v2f om = 1.0f - alpha;
+                const v2f rinv = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };   // one v_rcp per pixel
+                T = T * rinv;
+                const v2f dchan = alpha * T;
+                const v2f oml = 1.0f - last_alpha;
+                acr = last_alpha * lcr + oml * acr;
+                acg = last_alpha * lcg + oml * acg;
+                acb = last_alpha * lcb + oml * acb;
+                lcr = v2f{ c.x, c.x }; lcg = v2f{ c.y, c.y }; lcb = v2f{ c.z, c.z };
+                last_alpha = alpha;
+                v2f dL_dalpha = (c.x - acr) * dLr + (c.y - acg) * dLg + (c.z - acb) * dLb;
+                dL_dalpha = dL_dalpha * T - bgT * rinv;
+                const v2f dop = G * dL_dalpha;                    // G * dL/dalpha
+                const v2f sG = b.z * dop;                         // (o * dL/dalpha) * G
+                const v2f sdx = sG * dx, sdy = sG * dy;
+                const v2f t_dmx = (-a.z * sdx - a.w * sdy) * ddelx_dx;
+                const v2f t_dmy = (-b.x * sdy - a.w * sdx) * ddely_dy;
+                const v2f t_dca = -0.5f * sdx * dx, t_dcb = -0.5f * sdx * dy, t_dcc = -0.5f * sdy * dy;
+                const v2f t_dr = dchan * dLr, t_dg = dchan * dLg, t_db = dchan * dLb;
+                // the lane's two pixels add up first, then the wave reduction of the nine terms
+                const float ra = reduce4(t_dmx.x + t_dmx.y, t_dmy.x + t_dmy.y, t_dca.x + t_dca.y, t_dcb.x + t_dcb.y);
+                const float rb = reduce4(t_dcc.x + t_dcc.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
+                const float rc = row_sum(t_db.x + t_db.y);        // every row: its partial of db
                 float* dst = s_acc[j];
-                if (row_leader) { atomicAdd(dst + col_a, ra); atomicAdd(dst + col_b, rb); atomicAdd(dst + 8, rc); }
+                if (row_leader) {
+                    atomicAdd(dst + col_a, ra);
+                    atomicAdd(dst + col_b, rb);
+                    atomicAdd(dst + 8 + opaque_zero, rc);
+                }
             }
         }
         __syncthreads();
@@ -262,7 +273,7 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int grid = ((num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
+    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(BATCH), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
                        final_T, n_contrib, dL_dpix, bin_base, hdr);
 }
 
