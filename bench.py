@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
     ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the views of a step alternate on (forward of view i+1 overlaps backward of view i)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
                     help="let autograd accumulate dense per-view gradients instead of the in-kernel accumulation")
     args = ap.parse_args()
@@ -138,13 +140,18 @@ def main():
 
     m2d_grad = torch.zeros(P, 3, device=dev)
 
+    pipe = parallel.ViewStreams(dev, args.streams)
+
     def step():
         grads.zero_()
         means2D.grad = m2d_grad.zero_() if not args.no_fused_accumulate else None
+        pipe.begin_step()
         for r in rasterizers:
-            color, radii, depth = r(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
-                                    shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
-            color.backward(grad_color)
+            pipe.run_view(
+                lambda r=r: r(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
+                              shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0],
+                lambda color: color.backward(grad_color))
+        pipe.end_step()
         grads.all_reduce()
 
     def barrier():
@@ -212,7 +219,7 @@ def main():
             "config": {"workload": wl_name, "views_per_rank_per_step": V, "gaussians": P, "visible_mean": round(V_mean, 1),
                        "num_rendered_mean": round(R_mean, 1), "sh_degree": degree, "resolution": [W, H],
                        "mode": "exact (host sync per view)" if args.exact else "async (no host sync per view)",
-                       "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)",
+                       "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)", "streams_per_rank": args.streams,
                        "grad_bucket_bytes": int(grads.flat.numel() * 4)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

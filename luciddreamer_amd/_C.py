@@ -46,6 +46,8 @@ def _f32(t, device, name):
     RAST/.../__init__.py:198-208) become None."""
     if t is None or t.numel() == 0:
         return None
+    if t.dtype is torch.float32 and t.device == device and t.is_contiguous():
+        return t                                            # the common case: nothing to do
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
     if t.device != device:
@@ -59,6 +61,22 @@ def _ptr(t):
 
 def _stream(device):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when dev is not already current (the context manager costs ~5 us)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == dev.index else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -95,7 +113,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     call = {"device": dev, "bufs": [None, None, None]}
     _tls.call = call
     try:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = L.lr_forward(_ALLOC, 0, _ALLOC, 1, _ALLOC, 2, P, int(degree), M, _ptr(bg), W, H,
                               _ptr(means3D_c), _ptr(sh_c), _ptr(colors_c), _ptr(opacity_c), _ptr(scales_c),
                               float(scale_modifier), _ptr(rot_c), _ptr(cov_c), _ptr(view), _ptr(proj), _ptr(cam),
@@ -175,7 +193,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         g_color = _f32(dL_dout_color, dev, "dL_dout_color")
         g_depth = _f32(dL_dout_depth, dev, "dL_dout_depth") if dL_dout_depth is not None else None
         radii_c = radii.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = L.lr_backward(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(means3D_c), _ptr(sh_c),
                                _ptr(colors_c), _ptr(scales_c), float(scale_modifier), _ptr(rot_c), _ptr(cov_c),
                                _ptr(view), _ptr(proj), _ptr(cam), float(tan_fovx), float(tan_fovy),
@@ -200,7 +218,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
         m = _f32(means3D, dev, "means3D")
         v = _f32(viewmatrix, dev, "viewmatrix")
         p = _f32(projmatrix, dev, "projmatrix")
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().lr_mark_visible(P, m.data_ptr(), v.data_ptr(), p.data_ptr(), present.data_ptr(), _stream(dev))
         if rc < 0:
             _lib.raise_for(rc, "mark_visible")
@@ -212,7 +230,7 @@ def check(geomBuffer):
     import ctypes
     n = ctypes.c_longlong(0)
     dev = geomBuffer.device
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = _lib.lib().lr_check(geomBuffer.data_ptr(), ctypes.byref(n), _stream(dev))
     if rc < 0:
         _lib.raise_for(rc, "check")

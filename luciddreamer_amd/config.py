@@ -17,13 +17,18 @@ _fused_accumulate = False
 _headroom = 1.3
 _hwm = {}            # (device, P, H, W) -> largest num_rendered observed
 _pending = []        # [(event, pinned_header, key)]
-_POLL_EVERY = 1
+_CHECK_EVERY = 8      # async mode: every k-th forward gets its header copied back and checked
+_calls = 0
+_pinned_pool = []
 
 
-def set_async(enabled: bool, headroom: float = 1.3):
-    global _async, _headroom
+def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 8):
+    """check_every: every k-th async forward has its header (true instance count, overflow flag) copied back
+    without blocking and examined on a later call; 1 checks every view."""
+    global _async, _headroom, _CHECK_EVERY
     _async = bool(enabled)
     _headroom = float(headroom)
+    _CHECK_EVERY = max(1, int(check_every))
     if not enabled:
         drain()
 
@@ -64,7 +69,8 @@ def _poll(block=False):
         if block:
             ev.synchronize()
         _pending.pop(0)
-        num_rendered, overflow, trap = int(host[0]), int(host[1]), int(host[2])
+        num_rendered, overflow, trap = int(host[6]), int(host[1]), int(host[2])     # [6] = instances actually emitted
+        _pinned_pool.append(host)
         if num_rendered > _hwm.get(key, 0):
             _hwm[key] = num_rendered
         if trap:
@@ -100,7 +106,11 @@ def note_forward(means3D, rs, num_rendered, geom, capacity):
         if num_rendered > _hwm.get(key, 0):
             _hwm[key] = num_rendered
         return
-    host = torch.empty((8,), dtype=torch.int32, pin_memory=True)
+    global _calls
+    _calls += 1
+    if _calls % _CHECK_EVERY:
+        return
+    host = _pinned_pool.pop() if _pinned_pool else torch.empty((8,), dtype=torch.int32, pin_memory=True)
     host.copy_(geom[:32].view(torch.int32), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(means3D.device))

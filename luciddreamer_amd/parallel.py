@@ -104,6 +104,45 @@ def all_reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torc
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
 
 
+class ViewStreams:
+    """Round-robin HIP streams for the consecutive views of one rank.
+
+    The forward of a view is a chain of ~25 short, launch-latency-bound kernels (sorts, scans) followed by
+    the blend; the backward is two long kernels.  Putting consecutive views on alternating streams lets the
+    hardware run forward(i+1) underneath backward(i).  Backward passes are chained with an event because they
+    accumulate into the same gradient buffers (FlatGrads); forwards only read the parameters.
+    """
+
+    def __init__(self, device, n_streams: int = 2):
+        self.device = device
+        self.streams = [torch.cuda.Stream(device) for _ in range(max(1, n_streams))]
+        self._i = 0
+        self._prev_bwd = None
+
+    def begin_step(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+        self._prev_bwd = None
+
+    def run_view(self, forward_fn: Callable, backward_fn: Callable):
+        s = self.streams[self._i % len(self.streams)]
+        self._i += 1
+        with torch.cuda.stream(s):
+            out = forward_fn()
+            if self._prev_bwd is not None:
+                s.wait_event(self._prev_bwd)
+            backward_fn(out)
+            ev = torch.cuda.Event()
+            ev.record(s)
+            self._prev_bwd = ev
+
+    def end_step(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
 def dp_step(views: Sequence, params: Sequence[torch.Tensor], loss_fn: Callable, grads: Optional[FlatGrads] = None,
             rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True) -> FlatGrads:
     """One data-parallel gradient step over `views`.

@@ -242,3 +242,48 @@ def test_fused_grad_accumulation_equals_autograd(hip_device):
     for k in a:
         scale = np.abs(a[k]).max()
         assert scale > 0 and np.abs(a[k] - b[k]).max() <= 2e-5 * scale, k   # float atomics reorder sums run to run
+
+
+def test_two_stream_view_pipeline_equals_sequential(hip_device):
+    """parallel.ViewStreams: forward(i+1) may overlap backward(i) on another stream; the accumulated gradients
+    must equal the single-stream result (backward passes are chained by events)."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import config, parallel
+    cloud = synthetic.make_cloud(30_000, "band", 4)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(320, 180, n_views=8)]
+    g = synthetic.upstream_grad(180, 320).to(hip_device)
+    bg = torch.zeros(3, device=hip_device)
+
+    def run(n_streams):
+        leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
+        grads = parallel.FlatGrads(list(leaf.values()))
+        m2d = torch.zeros(30_000, 3, device=hip_device, requires_grad=True)
+        m2d.grad = torch.zeros_like(m2d)
+        rast = []
+        for c in cams:
+            tfx, tfy = hp.tan_fov(c)
+            rast.append(GaussianRasterizer(GaussianRasterizationSettings(
+                180, 320, tfx, tfy, bg, 1.0, c.world_view_transform, c.full_proj_transform, 3, c.camera_center,
+                False, False)))
+        config.set_fused_grad_accumulation(True)
+        try:
+            pipe = parallel.ViewStreams(hip_device, n_streams)
+            for _ in range(2):                      # two steps: buffers and events are re-used
+                grads.zero_()
+                m2d.grad.zero_()
+                pipe.begin_step()
+                for r in rast:
+                    pipe.run_view(lambda r=r: r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                                shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0],
+                                  lambda col: col.backward(g))
+                pipe.end_step()
+            torch.cuda.synchronize()
+        finally:
+            config.set_fused_grad_accumulation(False)
+        return grads.flat.cpu().numpy().copy(), m2d.grad.cpu().numpy().copy()
+
+    (f1, m1), (f2, m2) = run(1), run(2)
+    assert np.abs(f1).max() > 0
+    # the per-Gaussian sums run in a fixed order; only the 2-wave LDS adds inside a tile can reorder
+    assert np.abs(f1 - f2).max() <= 1e-5 * np.abs(f1).max()
+    assert np.abs(m1 - m2).max() <= 1e-5 * np.abs(m1).max()
