@@ -66,7 +66,10 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
     ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--api", default="views", choices=["views", "autograd"],
+                    help="views: one lr_views_accumulate call per step (parallel.ViewBatch); autograd: the drop-in "
+                         "GaussianRasterizer autograd op per view (parallel.ViewStreams)")
+    ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the views of a step alternate on (forward of view i+1 overlaps backward of view i)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
                     help="let autograd accumulate dense per-view gradients instead of the in-kernel accumulation")
@@ -141,9 +144,20 @@ def main():
     m2d_grad = torch.zeros(P, 3, device=dev)
 
     pipe = parallel.ViewStreams(dev, args.streams)
+    batch = None
+    if args.api == "views":
+        cap = int(max(s[0] for s in view_stats) * 1.25) + 4096
+        batch = parallel.ViewBatch(cams, [grad_color] * len(cams), degree, bg, cap, n_streams=args.streams)
+        acc = {"means3D": leaf["means3D"].grad, "means2D": m2d_grad, "opacity": leaf["opacities"].grad,
+               "sh": leaf["shs"].grad, "scales": leaf["scales"].grad, "rotations": leaf["rotations"].grad}
 
     def step():
         grads.zero_()
+        if batch is not None:                       # one C call: all views, fwd+bwd, accumulate in place
+            m2d_grad.zero_()
+            batch.run(leaf["means3D"], leaf["opacities"], leaf["scales"], leaf["rotations"], leaf["shs"], acc)
+            grads.all_reduce()
+            return
         means2D.grad = m2d_grad.zero_() if not args.no_fused_accumulate else None
         pipe.begin_step()
         for r in rasterizers:
@@ -177,11 +191,18 @@ def main():
         step()
     dt = timed(args.steps)
     config.drain()
+    if batch is not None:
+        batch.check()
     views_total = world * V * args.steps
     value = views_total / dt
     ms_per_step = dt / args.steps * 1e3
 
-    # ---- roofline leg: same steps again with per-stage HIP events recorded on the launch stream ----
+    # ---- roofline leg: the same steps again, on ONE stream so that kernels do not overlap, with per-stage
+    # HIP events recorded on the launch stream (each blend / per-Gaussian stage is exactly one kernel launch)
+    if batch is not None:
+        batch.n_streams = 1
+    pipe = parallel.ViewStreams(dev, 1)
+    step()
     _lib.profile_enable(True)
     dt_prof = timed(args.steps)
     stages = _lib.profile_read()
@@ -204,6 +225,7 @@ def main():
         "path_frac_of_hbm_peak": round((b_f + b_b) * per_rank_views_s / (HBM_PEAK_GBS * 1e9), 5),
         "stage_ms_per_view": {k: round(v[0] / max(V * args.steps, 1), 4) for k, v in stages.items()},
         "instrumented_views_per_s": round(world * V * args.steps / dt_prof, 2),
+        "measured_with_streams": 1,
     }
 
     cpu_baseline = None
@@ -219,7 +241,7 @@ def main():
             "config": {"workload": wl_name, "views_per_rank_per_step": V, "gaussians": P, "visible_mean": round(V_mean, 1),
                        "num_rendered_mean": round(R_mean, 1), "sh_degree": degree, "resolution": [W, H],
                        "mode": "exact (host sync per view)" if args.exact else "async (no host sync per view)",
-                       "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)", "streams_per_rank": args.streams,
+                       "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)", "streams_per_rank": args.streams, "api": args.api,
                        "grad_bucket_bytes": int(grads.flat.numel() * 4)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,

@@ -160,6 +160,33 @@ int lr_backward(int P, int D, int M, int R,
                 unsigned int accumulate_mask,
                 void* stream);
 
+/*
+ * Multi-view step (new; the reference renders one view per Python iteration, luciddreamer.py:291-304).
+ * Runs lr_forward + lr_backward for n_views views of ONE parameter set and ACCUMULATES the gradients into the
+ * acc_* buffers (same shapes as lr_backward's outputs; acc_color / acc_cov3D / acc_sh / acc_scale / acc_rot may be
+ * NULL when the corresponding input is absent).  Everything is enqueued from C in one call: views alternate over
+ * up to 4 internal HIP streams (forward of view i+1 overlaps the backward of view i; the accumulating kernels
+ * are chained by events) which are forked from / joined to `stream` with events -- no host synchronisation.
+ * Async mode only (binning_capacity > 0); an overflow of any view is latched per slot and reported by
+ * lr_views_check (which synchronises).  Per-view arrays are HOST arrays of length n_views holding DEVICE
+ * pointers (viewmatrices, projmatrices, cam_positions, dL_dpix [3,H,W], optional out_color [3,H,W] and
+ * out_radii [P], entries or whole arrays may be NULL) or floats (tan_fovx, tan_fovy).
+ * workspace: lr_views_workspace_bytes(P, W, H, binning_capacity, n_streams) device bytes, 256-byte aligned.
+ */
+size_t lr_views_workspace_bytes(int P, int width, int height, long long binning_capacity, int n_streams);
+int lr_views_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+                        const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
+                        int P, int D, int M, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* const* dL_dpix, float* const* out_color, int* const* out_radii,
+                        float* acc_mean2D, float* acc_opacity, float* acc_color, float* acc_mean3D, float* acc_cov3D,
+                        float* acc_sh, float* acc_scale, float* acc_rot,
+                        char* workspace, size_t workspace_bytes, long long binning_capacity, int n_streams,
+                        void* stream);
+int lr_views_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                   void* stream);
+
 /* present[P] (1 byte each) = view-space z > 0.2.  Returns 0 or a negative LR_ERR_*. */
 int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream);

@@ -25,7 +25,8 @@ _lock = threading.Lock()
 
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
            "lr_backward", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
-           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read")
+           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
+           "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check")
 
 
 def lib():
@@ -73,6 +74,17 @@ def lib():
         L.lr_dist2_workspace_bytes.argtypes = [ci]
         L.lr_dist2.restype = ci
         L.lr_dist2.argtypes = [ci, vp, vp, vp, vp]
+        L.lr_views_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_views_workspace_bytes.argtypes = [ci, ci, ci, ll, ci]
+        L.lr_views_accumulate.restype = ci
+        L.lr_views_accumulate.argtypes = [ci, vp, vp, vp, vp, vp,                # n_views, view/proj/campos arrays, tanfovx/y arrays
+                                          ci, ci, ci, vp, ci, ci,                # P D M bg W H
+                                          vp, vp, vp, vp, vp, cf, vp, vp,        # means3D shs colors opac scales mod rot cov3D
+                                          vp, vp, vp,                            # dL_dpix[], out_color[], out_radii[]
+                                          vp, vp, vp, vp, vp, vp, vp, vp,        # 8 accumulators
+                                          vp, ctypes.c_size_t, ll, ci, vp]       # workspace, bytes, capacity, n_streams, stream
+        L.lr_views_check.restype = ci
+        L.lr_views_check.argtypes = [vp, ci, ci, ci, ll, ci, vp]
         L.lr_profile_enable.restype = ci
         L.lr_profile_enable.argtypes = [ci]
         L.lr_profile_stage_name.restype = ctypes.c_char_p

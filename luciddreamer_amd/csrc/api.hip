@@ -7,6 +7,7 @@
 #include "../../include/lucid_raster.h"
 
 #include <cstdio>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -136,7 +137,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     uint2* ranges = reinterpret_cast<uint2*>(img + IL.ranges);
 
     // header starts zeroed; the preprocess kernel fills in {capacity, P}
-    LR_HIP_CHECK(hipMemsetAsync(hdr, 0, sizeof(GeomHeader), s));
+    LR_HIP_CHECK(hipMemsetAsync(hdr, 0, offsetof(GeomHeader, sticky_overflow), s));
 
     ViewParams vp;
     vp.view = viewmatrix; vp.proj = projmatrix; vp.campos = cam_pos;
@@ -247,7 +248,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     return num_rendered;
 }
 
-int lr_backward(int P, int D, int M, int R, const float* background, int width, int height,
+static int backward_core(int P, int D, int M, int R, const float* background, int width, int height,
                 const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
                 const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
@@ -255,7 +256,7 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
                 const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                 float* dL_dscale, float* dL_drot, int debug, long long binning_capacity,
-                unsigned int accumulate_mask, void* stream_)
+                unsigned int accumulate_mask, void* stream_, hipEvent_t wait_before_accumulate)
 {
     using namespace lr;
     (void)dL_depths;   // ignored, as in the reference (backward.cu:457-464, 539-554 commented out)
@@ -299,6 +300,8 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
     launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix,
                       binning_buffer, hdr, s); }
     LR_DEBUG_SYNC(debug, s, "render backward");
+    // another stream may still be accumulating into the same gradient tensors (lr_views_accumulate)
+    if (wait_before_accumulate != nullptr) LR_HIP_CHECK(hipStreamWaitEvent(s, wait_before_accumulate, 0));
     {   // tensors in write mode are zero-filled here (one launch); accumulate-mode tensors are left alone
         ProfScope ps(ST_OUT_ZERO, s);
         const unsigned long long Pn = (unsigned long long)P;
@@ -316,6 +319,162 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
                      dL_drot, accumulate_mask, s); }
     LR_DEBUG_SYNC(debug, s, "preprocess backward");
     LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int lr_backward(int P, int D, int M, int R, const float* background, int width, int height,
+                const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
+                float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
+                float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
+                float* dL_dscale, float* dL_drot, int debug, long long binning_capacity,
+                unsigned int accumulate_mask, void* stream_)
+{
+    return backward_core(P, D, M, R, background, width, height, means3D, shs, colors_precomp, scales, scale_modifier,
+                         rotations, cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii,
+                         geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dconic,
+                         dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
+                         binning_capacity, accumulate_mask, stream_, nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Multi-view step: forward + backward of n_views views of one parameter set, gradients ACCUMULATED into the
+// caller's buffers, entirely enqueued from C (one call per optimisation step instead of 2 calls per view).
+// Views alternate over internal HIP streams so that the launch-latency-bound forward of view i+1 runs under
+// the two long backward kernels of view i; the accumulating kernel of view i+1 waits (event) for view i's.
+// The caller's stream is forked at entry and joined at exit with events -- no host synchronisation.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kMaxViewStreams = 4;
+struct ViewSlot { size_t geom, img, bin, color, depth, radii, total; };
+ViewSlot view_slot_layout(int P, int W, int H, long long capacity)
+{
+    ViewSlot L; size_t o = 0;
+    const size_t N = (size_t)W * H;
+    L.geom = o;  o += lr::geom_layout(P).total;
+    L.img = o;   o += lr::img_layout(W, H).total;
+    L.bin = o;   o += lr::bin_layout(capacity).total;
+    L.color = o; o += lr::align_up(3 * N * 4);
+    L.depth = o; o += lr::align_up(N * 4);
+    L.radii = o; o += lr::align_up((size_t)(P > 0 ? P : 1) * 4);
+    L.total = o;
+    return L;
+}
+struct SliceCookie { char* ptr; size_t bytes; };
+char* slice_alloc(size_t bytes, void* user)
+{
+    SliceCookie* c = static_cast<SliceCookie*>(user);
+    return bytes <= c->bytes ? c->ptr : nullptr;
+}
+hipStream_t g_view_streams[kMaxViewStreams] = { nullptr, nullptr, nullptr, nullptr };
+hipEvent_t g_view_events[2 * kMaxViewStreams + 2] = {};
+}  // namespace
+
+size_t lr_views_workspace_bytes(int P, int width, int height, long long binning_capacity, int n_streams)
+{
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
+    return view_slot_layout(P, width, height, binning_capacity).total * (size_t)n_streams;
+}
+
+int lr_views_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+                        const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
+                        int P, int D, int M, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* const* dL_dpix, float* const* out_color, int* const* out_radii,
+                        float* acc_mean2D, float* acc_opacity, float* acc_color, float* acc_mean3D, float* acc_cov3D,
+                        float* acc_sh, float* acc_scale, float* acc_rot,
+                        char* workspace, size_t workspace_bytes, long long binning_capacity, int n_streams,
+                        void* stream_)
+{
+    using namespace lr;
+    hipStream_t caller = reinterpret_cast<hipStream_t>(stream_);
+    if (n_views <= 0 || P <= 0) return 0;
+    if (binning_capacity <= 0) return fail(LR_ERR_INVALID_ARG, "lr_views_accumulate runs in async mode: binning_capacity > 0 is required");
+    if (!viewmatrices || !projmatrices || !cam_positions || !tan_fovx || !tan_fovy || !dL_dpix || !workspace)
+        return fail(LR_ERR_INVALID_ARG, "per-view arrays and workspace are required");
+    if (!acc_mean2D || !acc_opacity || !acc_mean3D) return fail(LR_ERR_INVALID_ARG, "acc_mean2D/acc_opacity/acc_mean3D are required");
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
+    if (n_streams > n_views) n_streams = n_views;
+    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity);
+    if (workspace_bytes < SL.total * (size_t)n_streams) return fail(LR_ERR_INVALID_ARG, "workspace too small (lr_views_workspace_bytes)");
+
+    for (int i = 0; i < n_streams; i++)
+        if (!g_view_streams[i]) LR_HIP_CHECK(hipStreamCreateWithFlags(&g_view_streams[i], hipStreamNonBlocking));
+    for (int i = 0; i < 2 * kMaxViewStreams + 2; i++)
+        if (!g_view_events[i]) LR_HIP_CHECK(hipEventCreateWithFlags(&g_view_events[i], hipEventDisableTiming));
+    hipEvent_t ev_fork = g_view_events[0];
+    hipEvent_t* ev_bwd = &g_view_events[1];                     // ring of n_streams + 1 "accumulation done" events
+    hipEvent_t* ev_join = &g_view_events[2 + kMaxViewStreams];
+
+    // sticky per-slot overflow words (see GeomHeader::sticky_overflow) start at zero; fork the streams
+    for (int i = 0; i < n_streams; i++) {
+        GeomHeader* hdr = reinterpret_cast<GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
+        LR_HIP_CHECK(hipMemsetAsync(&hdr->sticky_overflow, 0, 4, caller));
+    }
+    LR_HIP_CHECK(hipEventRecord(ev_fork, caller));
+    for (int i = 0; i < n_streams; i++) LR_HIP_CHECK(hipStreamWaitEvent(g_view_streams[i], ev_fork, 0));
+
+    unsigned int mask = LR_ACC_MEAN2D | LR_ACC_OPACITY | LR_ACC_MEAN3D;
+    if (acc_color) mask |= LR_ACC_COLOR;
+    if (acc_cov3D) mask |= LR_ACC_COV3D;
+    if (acc_sh) mask |= LR_ACC_SH;
+    if (acc_scale) mask |= LR_ACC_SCALE;
+    if (acc_rot) mask |= LR_ACC_ROT;
+
+    hipEvent_t prev = nullptr;
+    for (int v = 0; v < n_views; v++) {
+        const int si = v % n_streams;
+        hipStream_t s = g_view_streams[si];
+        char* slot = workspace + (size_t)si * SL.total;
+        SliceCookie cg = { slot + SL.geom, SL.img - SL.geom }, ci = { slot + SL.img, SL.bin - SL.img },
+                    cb = { slot + SL.bin, SL.color - SL.bin };
+        float* color = (out_color && out_color[v]) ? out_color[v] : reinterpret_cast<float*>(slot + SL.color);
+        float* depth = reinterpret_cast<float*>(slot + SL.depth);
+        int* radii = (out_radii && out_radii[v]) ? out_radii[v] : reinterpret_cast<int*>(slot + SL.radii);
+        int rc = lr_forward(slice_alloc, &cg, slice_alloc, &cb, slice_alloc, &ci, P, D, M, background, width, height,
+                            means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                            viewmatrices[v], projmatrices[v], cam_positions[v], tan_fovx[v], tan_fovy[v], 0, color, depth,
+                            radii, 0, binning_capacity, s);
+        if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) return rc;
+        rc = backward_core(P, D, M, LR_NUM_RENDERED_ON_DEVICE, background, width, height, means3D, shs, colors_precomp,
+                           scales, scale_modifier, rotations, cov3D_precomp, viewmatrices[v], projmatrices[v],
+                           cam_positions[v], tan_fovx[v], tan_fovy[v], radii, slot + SL.geom, slot + SL.bin, slot + SL.img,
+                           dL_dpix[v], nullptr, acc_mean2D, nullptr, acc_opacity, acc_color, acc_mean3D, acc_cov3D, acc_sh,
+                           acc_scale, acc_rot, 0, binning_capacity, mask, s, prev);
+        if (rc < 0) return rc;
+        hipEvent_t done = ev_bwd[v % (n_streams + 1)];
+        LR_HIP_CHECK(hipEventRecord(done, s));
+        prev = done;
+    }
+    for (int i = 0; i < n_streams; i++) {
+        LR_HIP_CHECK(hipEventRecord(ev_join[i], g_view_streams[i]));
+        LR_HIP_CHECK(hipStreamWaitEvent(caller, ev_join[i], 0));
+    }
+    return 0;
+}
+
+int lr_views_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                   void* stream_)
+{
+    using namespace lr;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!workspace) return fail(LR_ERR_INVALID_ARG, "NULL workspace");
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
+    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity);
+    uint32_t flags[kMaxViewStreams] = { 0, 0, 0, 0 };
+    for (int i = 0; i < n_streams; i++) {
+        const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
+        LR_HIP_CHECK(hipMemcpyAsync(&flags[i], &hdr->sticky_overflow, 4, hipMemcpyDeviceToHost, s));
+    }
+    LR_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < n_streams; i++)
+        if (flags[i]) return fail(LR_ERR_OVERFLOW, "binning capacity exceeded by at least one view of the step");
     return 0;
 }
 

@@ -329,6 +329,7 @@ k_scan_write(const GeomHeader* __restrict__ hdr_in, const uint32_t* __restrict__
         hdr->num_instances = total;
         const bool over = (hdr->capacity != 0 && total > hdr->capacity);
         hdr->overflow = over ? 1u : 0u;
+        if (over) hdr->sticky_overflow = 1u;
         hdr->num_sorted = over ? hdr->capacity : total;
     }
 }

@@ -41,7 +41,9 @@ struct GeomHeader {
     uint32_t num_instances;         // tile instances after exact tile culling (what is emitted and sorted)
     uint32_t bin_bound;             // instance count the binning buffer was laid out for (R or capacity)
     uint32_t num_compact;           // Gaussians that emit at least one instance (length of the compacted arrays)
-    uint32_t reserved[55];
+    uint32_t reserved[51];
+    uint32_t sticky_overflow;       // set (never cleared by lr_forward) when a view overflowed: lr_views_accumulate / lr_views_check
+    uint32_t reserved_tail[3];
 };
 static_assert(sizeof(GeomHeader) == 256, "GeomHeader must be 256 bytes");
 

@@ -143,6 +143,81 @@ class ViewStreams:
             cur.wait_stream(s)
 
 
+class ViewBatch:
+    """One C call per step for a fixed list of views (lr_views_accumulate): forward + backward of every view,
+    gradients accumulated in place, views alternated over internal HIP streams.  The per-view upstream
+    gradients dL/dcolor are given up front (a training loop that needs the rendered image to form its loss uses
+    the autograd op, optionally with ViewStreams, instead).
+
+    cams: objects with world_view_transform, full_proj_transform, camera_center (device tensors), FoVx, FoVy,
+          image_width, image_height (e.g. cameras.MiniCam); all views share one resolution.
+    """
+
+    def __init__(self, cams: Sequence, grad_colors: Sequence[torch.Tensor], sh_degree: int, bg: torch.Tensor,
+                 binning_capacity: int, n_streams: int = 2, scale_modifier: float = 1.0):
+        import ctypes
+        import math
+        from . import _lib
+        self._lib = _lib
+        self.L = _lib.lib()
+        self.cams = list(cams)
+        self.n = len(self.cams)
+        assert self.n == len(grad_colors) and self.n > 0
+        self.W, self.H = int(self.cams[0].image_width), int(self.cams[0].image_height)
+        self.device = self.cams[0].world_view_transform.device
+        self.degree, self.scale_modifier = int(sh_degree), float(scale_modifier)
+        self.capacity, self.n_streams = int(binning_capacity), int(n_streams)
+        self.bg = bg.to(self.device).contiguous()
+        keep = []
+
+        def ptr_array(tensors):
+            ts = [t.to(self.device).contiguous() for t in tensors]
+            keep.extend(ts)
+            return (ctypes.c_void_p * self.n)(*[t.data_ptr() for t in ts])
+        self._views = ptr_array([c.world_view_transform for c in self.cams])
+        self._projs = ptr_array([c.full_proj_transform for c in self.cams])
+        self._campos = ptr_array([c.camera_center for c in self.cams])
+        self._grads = ptr_array(grad_colors)
+        self._tanx = (ctypes.c_float * self.n)(*[math.tan(c.FoVx * 0.5) for c in self.cams])
+        self._tany = (ctypes.c_float * self.n)(*[math.tan(c.FoVy * 0.5) for c in self.cams])
+        self._keep = keep
+        self._ws = None
+        self._ws_key = None
+
+    def run(self, means3D, opacities, scales, rotations, shs, acc: dict):
+        """acc: {"means3D", "means2D", "opacity", "sh", "scales", "rotations"} -> contiguous float32 tensors that are
+        accumulated into (e.g. the .grad views of a FlatGrads bucket)."""
+        P, M = int(means3D.shape[0]), int(shs.shape[1])
+        key = (P, self.capacity)
+        if self._ws_key != key:
+            nbytes = self.L.lr_views_workspace_bytes(P, self.W, self.H, self.capacity, self.n_streams)
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+            self._ws_key = key
+        for t in (means3D, opacities, scales, rotations, shs, *acc.values()):
+            if not (t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()):
+                raise RuntimeError("ViewBatch.run needs contiguous float32 tensors on the HIP device")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.L.lr_views_accumulate(
+            self.n, self._views, self._projs, self._campos, self._tanx, self._tany, P, self.degree, M,
+            self.bg.data_ptr(), self.W, self.H, means3D.data_ptr(), shs.data_ptr(), None, opacities.data_ptr(),
+            scales.data_ptr(), self.scale_modifier, rotations.data_ptr(), None, self._grads, None, None,
+            acc["means2D"].data_ptr(), acc["opacity"].data_ptr(), None, acc["means3D"].data_ptr(), None,
+            acc["sh"].data_ptr(), acc["scales"].data_ptr(), acc["rotations"].data_ptr(),
+            self._ws.data_ptr(), self._ws.numel(), self.capacity, self.n_streams, stream)
+        if rc < 0:
+            self._lib.raise_for(rc, "lr_views_accumulate")
+
+    def check(self):
+        """Synchronise and raise if any view of the previous run() overflowed the binning capacity."""
+        if self._ws is None:
+            return
+        P = self._ws_key[0]
+        rc = self.L.lr_views_check(self._ws.data_ptr(), P, self.W, self.H, self.capacity, self.n_streams,
+                                   torch.cuda.current_stream(self.device).cuda_stream)
+        if rc < 0:
+            self._lib.raise_for(rc, "lr_views_check")
+
+
 def dp_step(views: Sequence, params: Sequence[torch.Tensor], loss_fn: Callable, grads: Optional[FlatGrads] = None,
             rank: Optional[int] = None, world: Optional[int] = None, reduce: bool = True) -> FlatGrads:
     """One data-parallel gradient step over `views`.

@@ -287,3 +287,47 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     # the per-Gaussian sums run in a fixed order; only the 2-wave LDS adds inside a tile can reorder
     assert np.abs(f1 - f2).max() <= 1e-5 * np.abs(f1).max()
     assert np.abs(m1 - m2).max() <= 1e-5 * np.abs(m1).max()
+
+
+def test_view_batch_equals_autograd_accumulation(hip_device):
+    """parallel.ViewBatch (lr_views_accumulate: one C call, internal streams) == per-view autograd accumulation."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import parallel
+    cloud = synthetic.make_cloud(25_000, "band", 6)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(256, 160, n_views=7)]
+    g = synthetic.upstream_grad(160, 256).to(hip_device)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=hip_device)
+    leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
+    m2d = torch.zeros(25_000, 3, device=hip_device, requires_grad=True)
+    for c in cams:
+        tfx, tfy = hp.tan_fov(c)
+        rs = GaussianRasterizationSettings(160, 256, tfx, tfy, bg, 1.0, c.world_view_transform, c.full_proj_transform,
+                                           3, c.camera_center, False, False)
+        col, _, _ = GaussianRasterizer(rs)(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                           shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+        col.backward(g)
+    ref = {k: v.grad.clone() for k, v in leaf.items()}
+    ref["means2D"] = m2d.grad.clone()
+
+    acc = {"means3D": torch.zeros_like(leaf["means3D"]), "means2D": torch.zeros_like(m2d),
+           "opacity": torch.zeros_like(leaf["opacities"]), "sh": torch.zeros_like(leaf["shs"]),
+           "scales": torch.zeros_like(leaf["scales"]), "rotations": torch.zeros_like(leaf["rotations"])}
+    batch = parallel.ViewBatch(cams, [g] * len(cams), 3, bg, binning_capacity=400_000, n_streams=2)
+    with torch.no_grad():
+        for _ in range(2):                           # run twice: workspace / streams / events are re-used
+            for t in acc.values():
+                t.zero_()
+            batch.run(leaf["means3D"].detach(), leaf["opacities"].detach(), leaf["scales"].detach(),
+                      leaf["rotations"].detach(), leaf["shs"].detach(), acc)
+    batch.check()
+    names = {"means3D": "means3D", "means2D": "means2D", "opacity": "opacities", "sh": "shs", "scales": "scales",
+             "rotations": "rotations"}
+    for k, rk in names.items():
+        a, b = acc[k].cpu().numpy(), ref[rk].cpu().numpy()
+        assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), k
+    # too small a capacity is reported, never written out of bounds
+    small = parallel.ViewBatch(cams, [g] * len(cams), 3, bg, binning_capacity=500, n_streams=2)
+    small.run(leaf["means3D"].detach(), leaf["opacities"].detach(), leaf["scales"].detach(),
+              leaf["rotations"].detach(), leaf["shs"].detach(), acc)
+    with pytest.raises(RuntimeError, match="capacity"):
+        small.check()
