@@ -1,0 +1,117 @@
+"""GPU tests of the caller-side contract: render() the way LucidDreamer's loop calls it, and loss-curve parity of a
+short optimisation (BASELINE.json configs[4] shape at a size the CPU oracle can follow)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from luciddreamer_amd import cameras, synthetic
+from luciddreamer_amd.gaussian_renderer import GaussianCloud, render
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+
+
+def test_render_entry_contract(hip_device):
+    """render(viewpoint, pc, opt, bg) -> dict with the reference's keys; viewspace_points.grad feeds densification
+    (scene/gaussian_model.py:405-407); visibility_filter == radii > 0 (gaussian_renderer/__init__.py:97-104)."""
+    c = synthetic.make_cloud(20_000, "box", 2)
+    pc = GaussianCloud(c["means3D"].to(hip_device), c["scales"].to(hip_device), c["rotations"].to(hip_device),
+                       c["opacities"].to(hip_device), c["shs"].to(hip_device), active_sh_degree=2)
+    cam = cameras.identity_camera(320, 240).to(hip_device)
+    bg = torch.tensor([0.0, 0.0, 0.0], device=hip_device)
+    pkg = render(cam, pc, bg_color=bg)
+    assert set(pkg) == {"render", "viewspace_points", "visibility_filter", "radii", "depth"}
+    assert pkg["render"].shape == (3, 240, 320) and pkg["depth"].shape == (1, 240, 320)
+    assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
+    loss = (pkg["render"] - 0.5).abs().mean() + 0.1 * pkg["depth"].mean()      # a depth term adds no gradient
+    loss.backward()
+    vs = pkg["viewspace_points"].grad
+    assert vs is not None and vs.shape == (20_000, 3) and float(vs[:, 2].abs().max()) == 0.0
+    assert float(vs[~pkg["visibility_filter"]].abs().max()) == 0.0 and float(vs.abs().max()) > 0
+    for p in pc.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    only = render(cam, pc, bg_color=bg, render_only=True)
+    assert set(only) == {"render", "depth"}
+    # oracle parity through the activations (exp / sigmoid / normalize / cat happen in torch, as in the reference)
+    cloud_act = dict(means3D=pc.get_xyz.detach().cpu(), scales=pc.get_scaling.detach().cpu(),
+                     rotations=pc.get_rotation.detach().cpu(), opacities=pc.get_opacity.detach().cpu(),
+                     shs=pc.get_features.detach().cpu())
+    ref = hp.run_oracle(cloud_act, cameras.identity_camera(320, 240), 2, torch.zeros(3))
+    hip = dict(color=pkg["render"].detach().cpu().numpy(), depth=pkg["depth"].detach().cpu().numpy(),
+               radii=pkg["radii"].cpu().numpy())
+    hp.compare_forward(hip, ref)
+
+
+class _OracleRasterize(torch.autograd.Function):
+    """The CPU oracle as an autograd op (test infrastructure) so the same torch optimiser can drive both paths."""
+
+    @staticmethod
+    def forward(ctx, means3D, opacities, scales, rotations, shs, cam, degree, bg):
+        from oracle import oracle
+        tfx, tfy = hp.tan_fov(cam)
+        n = lambda t: t.detach().cpu().numpy()
+        res = oracle.forward(n(bg), n(means3D), None, n(opacities), n(scales), n(rotations), 1.0, None,
+                             n(cam.world_view_transform), n(cam.full_proj_transform), tfx, tfy, cam.image_height,
+                             cam.image_width, n(shs), degree, n(cam.camera_center))
+        ctx.res = res
+        return torch.from_numpy(res.color), torch.from_numpy(res.depth)
+
+    @staticmethod
+    def backward(ctx, g_color, g_depth):
+        from oracle import oracle
+        g = oracle.backward(ctx.res, g_color.contiguous().numpy())
+        t = torch.from_numpy
+        return t(g[3]), t(g[2]), t(g[6]), t(g[7]), t(g[5]), None, None, None
+
+
+def test_loss_curve_parity_short_optimisation(hip_device):
+    """40 Adam iterations (GSParams learning rates, arguments.py:19-34) towards fixed RGB targets over 4 views, driven
+    once through the HIP rasterizer and once through the CPU oracle: the loss curves must coincide."""
+    P, W, H, iters, degree = 6_000, 128, 96, 40, 1
+    cams = cameras.lookaround_path(W, H, n_views=4, max_yaw_deg=12.0, max_pitch_deg=6.0)
+    base = synthetic.make_cloud(P, "box", 11, scale_mult=2.0)
+    target_cloud = synthetic.make_cloud(P, "box", 11, scale_mult=2.0)
+    target_cloud["means3D"] = target_cloud["means3D"] + 0.02 * torch.randn(P, 3, generator=torch.Generator().manual_seed(3))
+    target_cloud["shs"][:, 0] += 0.3
+    bg = torch.zeros(3)
+    targets = [torch.from_numpy(hp.run_oracle(target_cloud, c, degree, bg)["color"]) for c in cams]
+    lrs = dict(means3D=1.6e-4, shs=2.5e-3, opacities=0.05, scales=5e-3, rotations=1e-3)
+
+    def optimise(device, use_hip):
+        raw = dict(means3D=base["means3D"].clone(), shs=base["shs"].clone(),
+                   opacities=torch.logit(base["opacities"].clamp(1e-4, 1 - 1e-4)), scales=torch.log(base["scales"]),
+                   rotations=base["rotations"].clone())
+        raw = {k: v.to(device).requires_grad_(True) for k, v in raw.items()}
+        opt = torch.optim.Adam([{"params": [v], "lr": lrs[k]} for k, v in raw.items()], eps=1e-15)
+        losses = []
+        for it in range(iters):
+            cam = cams[it % len(cams)]
+            act = dict(means3D=raw["means3D"], opacities=torch.sigmoid(raw["opacities"]), scales=torch.exp(raw["scales"]),
+                       rotations=torch.nn.functional.normalize(raw["rotations"]), shs=raw["shs"])
+            if use_hip:
+                from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+                cd = cam.to(device)
+                tfx, tfy = hp.tan_fov(cam)
+                rs = GaussianRasterizationSettings(H, W, tfx, tfy, bg.to(device), 1.0, cd.world_view_transform,
+                                                   cd.full_proj_transform, degree, cd.camera_center, False, False)
+                m2d = torch.zeros_like(act["means3D"], requires_grad=True)
+                color, _, _ = GaussianRasterizer(rs)(means3D=act["means3D"], means2D=m2d, opacities=act["opacities"],
+                                                     shs=act["shs"], scales=act["scales"], rotations=act["rotations"])
+            else:
+                color, _ = _OracleRasterize.apply(act["means3D"], act["opacities"], act["scales"], act["rotations"],
+                                                  act["shs"], cam, degree, bg)
+            loss = (color - targets[it % len(cams)].to(device)).abs().mean()
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+        return np.array(losses)
+
+    l_hip = optimise(hip_device, True)
+    l_ref = optimise(torch.device("cpu"), False)
+    assert l_ref[-4:].mean() < 0.9 * l_ref[:4].mean(), "the optimisation should make progress"
+    rel = np.abs(l_hip - l_ref) / l_ref
+    print("loss first/last (oracle)", l_ref[0], l_ref[-1], "max rel curve distance", rel.max())
+    assert rel.max() < 2e-3
