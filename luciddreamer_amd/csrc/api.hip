@@ -7,6 +7,7 @@
 #include "../../include/lucid_raster.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstddef>
 #include <cstring>
 #include <string>

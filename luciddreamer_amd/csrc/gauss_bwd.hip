@@ -340,12 +340,14 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
     }
 }
 
-// Each workgroup owns CHUNK consecutive Gaussians: it compacts the visible ones (radii > 0) into LDS and
-// then runs the heavy per-Gaussian backward with DENSE waves over that list.  With few visible Gaussians
+// Each single-wave workgroup owns GB_CHUNK consecutive Gaussians: it compacts the visible ones (radii > 0 and at
+// least one instance) into LDS with ballots and then runs the heavy per-Gaussian backward densely over that list.  With few visible Gaussians
 // (camera paths see ~10 % of a scene) a thread-per-Gaussian launch would run the full 200-VGPR body in
 // every wave for a handful of live lanes; here the body runs once per CHUNK/64 as many Gaussians, index
 // order (and with it coalescing of the row reads/writes) is preserved, and no global atomics are needed.
-constexpr int GB_CHUNK = 1024;
+constexpr int GB_CHUNK = 256;        // Gaussians per workgroup
+constexpr int GB_THREADS = 64;       // ONE wave per workgroup: the heavy body needs ~200 VGPRs (2 waves/SIMD), so small
+                                     // single-wave groups keep 4x more independent chunks in flight than 256-thread ones
 
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ float wave_sum(float v)
@@ -355,7 +357,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(GB_THREADS)
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
             const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
@@ -368,21 +370,17 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
 {
     constexpr uint32_t SERIAL_MAX = 24;      // instances summed by the owning lane; more -> whole wave helps
     __shared__ uint32_t s_list[GB_CHUNK];
-    __shared__ uint32_t s_count;
-    if (threadIdx.x == 0) s_count = 0;
-    __syncthreads();
     const int base = blockIdx.x * GB_CHUNK;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x;
+    uint32_t s_count = 0;                                   // wave-uniform running count
 #pragma unroll
-    for (int r = 0; r < GB_CHUNK / 256; r++) {
-        const int idx = base + r * 256 + (int)threadIdx.x;
+    for (int r = 0; r < GB_CHUNK / GB_THREADS; r++) {
+        const int idx = base + r * GB_THREADS + lane;
         // a visible Gaussian whose tiles were all culled has an all-zero gradient: nothing to do for it
         const bool vis = idx < vp.P && radii[idx] > 0 && tiles_touched[idx] != 0;
         const uint64_t m = __ballot(vis);
-        uint32_t pos = 0;
-        if (lane == 0 && m != 0) pos = atomicAdd(&s_count, (uint32_t)__popcll(m));
-        pos = __shfl(pos, 0);
-        if (vis) s_list[pos + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        if (vis) s_list[s_count + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        s_count += (uint32_t)__popcll(m);
     }
     __syncthreads();
     const uint32_t n = s_count;
@@ -393,7 +391,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         reinterpret_cast<const float4*>(bin_base + bin_layout((long long)hdr->bin_bound).inst_grad);
     const uint32_t n_slots = hdr->num_sorted;
 
-    for (uint32_t t0 = 0; t0 < n; t0 += 256) {
+    for (uint32_t t0 = 0; t0 < n; t0 += GB_THREADS) {
         const uint32_t t = t0 + threadIdx.x;
         const bool live = t < n;
         const int idx = live ? (int)s_list[t] : 0;
@@ -488,7 +486,7 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
 {
     (void)colors_precomp;
     if (vp.P <= 0) return;
-    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + GB_CHUNK - 1) / GB_CHUNK), dim3(256), 0, s, vp, means3D, scales, rotations, shs,
+    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + GB_CHUNK - 1) / GB_CHUNK), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
                        cov3D_precomp, radii, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                        dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
 }
