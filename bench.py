@@ -14,7 +14,7 @@ Inputs are resident in HBM before the timed region; data is synthetic (SURVEY.md
 Workloads (BASELINE.json configs):
   c3 (default; the metric's configuration): 1e6 Gaussians, SH degree 3, 1920x1080, band cloud,
       rotate360 camera path, V = 30 views per rank per step.
-  c2: 1e5 Gaussians, SH degree 3, 1920x1080, box cloud, single identity view repeated V times.
+  c2: 1e5 Gaussians, SH degree {degree}, {W}x{H}, box cloud, single identity view repeated V times.
 
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside the library
 on the launch stream) and `cpu_baseline` (the CPU oracle = "port" of the reference semantics, timed
@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
     ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resolution", default="1920x1080", help="WxH (the metric uses 1920x1080)")
     ap.add_argument("--sh-degree", type=int, default=3, choices=[0, 1, 2, 3], help="active SH degree (diagnostics; the metric uses 3)")
     ap.add_argument("--api", default="views", choices=["views", "autograd"],
                     help="views: one lr_views_accumulate call per step (parallel.ViewBatch); autograd: the drop-in "
@@ -85,21 +86,22 @@ def main():
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    W, H, degree = 1920, 1080, args.sh_degree
+    W, H = (int(v) for v in args.resolution.lower().split("x"))
+    degree = args.sh_degree
     if args.workload == "c3":
         P = args.gaussians or 1_000_000
         V = args.views or 30
         cloud = synthetic.make_cloud(P, "band", 0)
         path = cameras.rotate360_path(W, H, n_views=V * world)
         my_cams = [path[i] for i in parallel.shard_views(len(path), rank, world)]
-        wl_name = f"C3: {P} Gaussians, SH degree {degree}, 1920x1080, band cloud, rotate360 path, {V} views/rank/step"
+        wl_name = f"C3: {P} Gaussians, SH degree {degree}, {W}x{H}, band cloud, rotate360 path, {V} views/rank/step"
     else:
         P = args.gaussians or (100_000 if args.workload == "c2" else 1_000_000)
         V = args.views or 30
         cloud = synthetic.make_cloud(P, "box", 0)
         my_cams = [cameras.identity_camera(W, H)] * V
         tag = "C2" if args.workload == "c2" else "C3-box (all Gaussians in front of the camera)"
-        wl_name = f"{tag}: {P} Gaussians, SH degree 3, 1920x1080, box cloud, identity view x{V}/rank/step"
+        wl_name = f"{tag}: {P} Gaussians, SH degree {degree}, {W}x{H}, box cloud, identity view x{V}/rank/step"
     M = cloud["shs"].shape[1]
     K = NCOEF[degree]
     N = W * H

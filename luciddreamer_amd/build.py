@@ -57,7 +57,7 @@ def build(force=False, verbose=False):
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            cmd = [cc, "-c", sp, "-o", op] + COMMON_FLAGS + extra
+            cmd = [cc, "-c", sp, "-o", op] + COMMON_FLAGS + extra + os.environ.get("LR_EXTRA_HIPCC_FLAGS", "").split()
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

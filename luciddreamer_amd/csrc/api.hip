@@ -278,6 +278,7 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
     const uint8_t* clamped = reinterpret_cast<const uint8_t*>(geom_buffer + GL.clamped);
     const uint32_t* tiles_touched = reinterpret_cast<const uint32_t*>(geom_buffer + GL.tiles_touched);
     const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + GL.goff);
+    const uint32_t* vis_list = reinterpret_cast<const uint32_t*>(geom_buffer + GL.tiles_ref);   // see launch_compact
     const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(geom_buffer + GL.header);
     const float* final_T = reinterpret_cast<const float*>(image_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + IL.n_contrib);
@@ -314,7 +315,7 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
         launch_zero_outputs(zp, zn, zc, s);
     }
     { ProfScope ps(ST_GAUSS_BWD, s);
-    launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, radii, clamped, tiles_touched, goff,
+    launch_gauss_bwd(vp, means3D, scales, rotations, shs, cov3D_precomp, colors_precomp, vis_list, clamped, tiles_touched, goff,
                      binning_buffer, hdr,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
                      dL_drot, accumulate_mask, s); }

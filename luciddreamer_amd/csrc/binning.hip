@@ -217,7 +217,7 @@ k_compact_reduce(int P, const uint32_t* __restrict__ tiles_touched, const uint32
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ depth_key,
                 const uint2* __restrict__ block_sums, uint32_t* __restrict__ ckey, uint32_t* __restrict__ cidx,
-                GeomHeader* hdr)
+                uint32_t* __restrict__ vis_list, GeomHeader* hdr)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_wave[4];
@@ -254,7 +254,7 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint32_
     uint32_t run = pre + wbase + inc - sum;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
-        if (flag[i]) { ckey[run] = depth_key[base + i]; cidx[run] = (uint32_t)(base + i); run++; }
+        if (flag[i]) { ckey[run] = depth_key[base + i]; cidx[run] = (uint32_t)(base + i); vis_list[run] = (uint32_t)(base + i); run++; }
     }
     if (last_block && threadIdx.x == SCAN_THREADS - 1) {
         hdr->num_compact = run;
@@ -472,13 +472,15 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
     *vals_out = vin;
 }
 
-void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, const uint32_t* depth_key,
+void launch_compact(int P, const uint32_t* tiles_touched, uint32_t* tiles_ref, const uint32_t* depth_key,
                     uint2* block_sums, uint32_t* ckey, uint32_t* cidx, GeomHeader* hdr, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_compact_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, tiles_ref, block_sums);
+    // tiles_ref is dead once k_compact_reduce has totalled it: the same array then receives the index-ordered
+    // list of emitting Gaussians (the sort below destroys cidx), which the per-Gaussian backward walks
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, depth_key, block_sums,
-                       ckey, cidx, hdr);
+                       ckey, cidx, tiles_ref, hdr);
 }
 
 void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, const uint32_t* tiles_ref,

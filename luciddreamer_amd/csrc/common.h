@@ -96,7 +96,7 @@ inline GeomLayout geom_layout(int P) {
     L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
     L.hist = o;          o += sort_hist_bytes((long long)Pz);
     L.goff = o;          o += align_up(Pz * 4);
-    L.tiles_ref = o;     o += align_up(Pz * 4);
+    L.tiles_ref = o;     o += align_up(Pz * 4);      // after compaction: vis_list (ids of emitting Gaussians, index order)
     L.total = o;
     return L;
 }
@@ -203,7 +203,7 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
 
 // Order-preserving compaction of the Gaussians with tiles_touched != 0: (ckey, cidx) <- (depth_key, index);
 // count -> hdr->num_compact, sum of tiles_ref over all Gaussians -> hdr->num_rendered.
-void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, const uint32_t* depth_key,
+void launch_compact(int P, const uint32_t* tiles_touched, uint32_t* tiles_ref, const uint32_t* depth_key,
                     uint2* block_sums, uint32_t* ckey, uint32_t* cidx, GeomHeader* hdr, hipStream_t s);
 // offsets[k] = exclusive prefix of tiles_touched[order[k]], k in depth order; total -> hdr->num_instances
 // (and the overflow flag against hdr->capacity); sum of tiles_ref -> hdr->num_rendered (reference count).
@@ -224,7 +224,7 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
                        hipStream_t s);
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const int* radii, const uint8_t* clamped, const uint32_t* tiles_touched,
+                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* tiles_touched,
                       const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,

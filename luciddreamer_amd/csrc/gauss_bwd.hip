@@ -13,6 +13,7 @@
 //                touched at all -- this fuses autograd's `grad += new_grad` pass (another 3 x 236 B per
 //                Gaussian per view of HBM traffic) into the kernel when several views are accumulated.
 #include "common.h"
+#include <algorithm>
 
 namespace lr {
 
@@ -52,96 +53,84 @@ __device__ __forceinline__ V3 operator+(V3 a, V3 b) { return { a.x + b.x, a.y + 
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return { s * a.x, s * a.y, s * a.z }; }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 
-// Row store of `n` floats at dst (n*4 bytes per row).  Uses 16-byte stores when the row is aligned.
-template <int NMAX>
-__device__ __forceinline__ void store_row(float* __restrict__ dst, const float (&v)[NMAX], int n)
-{
-    if ((n & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-#pragma unroll
-        for (int q = 0; q < NMAX / 4; q++)
-            if (4 * q < n) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else {
-#pragma unroll
-        for (int q = 0; q < NMAX; q++)
-            if (q < n) dst[q] = v[q];
-    }
-}
-
-// SH backward for one Gaussian (backward.cu:20-139).  Fills dsh[0..3K) and returns dL/ddir.
+// SH basis values and their derivatives w.r.t. the (normalised) view direction, band by band
+// (the coefficients of backward.cu:20-139: dRGB/dx = sum_k dbx[k] * sh[k], dL/dsh[k] = b[k] * dL/dRGB).
 template <int DEG>
-__device__ __forceinline__ V3 sh_backward(const float* __restrict__ sh_row, V3 dir, V3 dL_dRGB, float (&dsh)[48])
+__device__ __forceinline__ void sh_basis(V3 dir, float (&b)[16], float (&bx)[16], float (&by)[16], float (&bz)[16])
 {
-    constexpr int K = (DEG + 1) * (DEG + 1);
-    V3 sh[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) sh[k] = { sh_row[3 * k], sh_row[3 * k + 1], sh_row[3 * k + 2] };
-    float basis[K];
     const float x = dir.x, y = dir.y, z = dir.z;
-    V3 dRGBdx = { 0, 0, 0 }, dRGBdy = { 0, 0, 0 }, dRGBdz = { 0, 0, 0 };
-    basis[0] = SH_C0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { b[k] = 0.f; bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; }
+    b[0] = SH_C0;
     if (DEG > 0) {
-        basis[1] = -SH_C1 * y; basis[2] = SH_C1 * z; basis[3] = -SH_C1 * x;
-        dRGBdx = -SH_C1 * sh[3];
-        dRGBdy = -SH_C1 * sh[1];
-        dRGBdz = SH_C1 * sh[2];
+        b[1] = -SH_C1 * y; by[1] = -SH_C1;
+        b[2] = SH_C1 * z;  bz[2] = SH_C1;
+        b[3] = -SH_C1 * x; bx[3] = -SH_C1;
         if (DEG > 1) {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            basis[4] = SH_C2[0] * xy; basis[5] = SH_C2[1] * yz; basis[6] = SH_C2[2] * (2.f * zz - xx - yy);
-            basis[7] = SH_C2[3] * xz; basis[8] = SH_C2[4] * (xx - yy);
-            dRGBdx = dRGBdx + ((SH_C2[0] * y) * sh[4] + (SH_C2[2] * 2.f * -x) * sh[6] + (SH_C2[3] * z) * sh[7] + (SH_C2[4] * 2.f * x) * sh[8]);
-            dRGBdy = dRGBdy + ((SH_C2[0] * x) * sh[4] + (SH_C2[1] * z) * sh[5] + (SH_C2[2] * 2.f * -y) * sh[6] + (SH_C2[4] * 2.f * -y) * sh[8]);
-            dRGBdz = dRGBdz + ((SH_C2[1] * y) * sh[5] + (SH_C2[2] * 2.f * 2.f * z) * sh[6] + (SH_C2[3] * x) * sh[7]);
+            b[4] = SH_C2[0] * xy;                    bx[4] = SH_C2[0] * y;        by[4] = SH_C2[0] * x;
+            b[5] = SH_C2[1] * yz;                    by[5] = SH_C2[1] * z;        bz[5] = SH_C2[1] * y;
+            b[6] = SH_C2[2] * (2.f * zz - xx - yy);  bx[6] = SH_C2[2] * 2.f * -x; by[6] = SH_C2[2] * 2.f * -y;
+            bz[6] = SH_C2[2] * 2.f * 2.f * z;
+            b[7] = SH_C2[3] * xz;                    bx[7] = SH_C2[3] * z;        bz[7] = SH_C2[3] * x;
+            b[8] = SH_C2[4] * (xx - yy);             bx[8] = SH_C2[4] * 2.f * x;  by[8] = SH_C2[4] * 2.f * -y;
             if (DEG > 2) {
-                basis[9] = SH_C3[0] * y * (3.f * xx - yy);
-                basis[10] = SH_C3[1] * xy * z;
-                basis[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
-                basis[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                basis[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
-                basis[14] = SH_C3[5] * z * (xx - yy);
-                basis[15] = SH_C3[6] * x * (xx - 3.f * yy);
-                dRGBdx = dRGBdx + ((SH_C3[0] * 3.f * 2.f * xy) * sh[9] + (SH_C3[1] * yz) * sh[10] + (SH_C3[2] * -2.f * xy) * sh[11]
-                                   + (SH_C3[3] * -3.f * 2.f * xz) * sh[12] + (SH_C3[4] * (-3.f * xx + 4.f * zz - yy)) * sh[13]
-                                   + (SH_C3[5] * 2.f * xz) * sh[14] + (SH_C3[6] * 3.f * (xx - yy)) * sh[15]);
-                dRGBdy = dRGBdy + ((SH_C3[0] * 3.f * (xx - yy)) * sh[9] + (SH_C3[1] * xz) * sh[10]
-                                   + (SH_C3[2] * (-3.f * yy + 4.f * zz - xx)) * sh[11] + (SH_C3[3] * -3.f * 2.f * yz) * sh[12]
-                                   + (SH_C3[4] * -2.f * xy) * sh[13] + (SH_C3[5] * -2.f * yz) * sh[14]
-                                   + (SH_C3[6] * -3.f * 2.f * xy) * sh[15]);
-                dRGBdz = dRGBdz + ((SH_C3[1] * xy) * sh[10] + (SH_C3[2] * 4.f * 2.f * yz) * sh[11]
-                                   + (SH_C3[3] * 3.f * (2.f * zz - xx - yy)) * sh[12] + (SH_C3[4] * 4.f * 2.f * xz) * sh[13]
-                                   + (SH_C3[5] * (xx - yy)) * sh[14]);
+                b[9] = SH_C3[0] * y * (3.f * xx - yy);
+                bx[9] = SH_C3[0] * 3.f * 2.f * xy;   by[9] = SH_C3[0] * 3.f * (xx - yy);
+                b[10] = SH_C3[1] * xy * z;
+                bx[10] = SH_C3[1] * yz;              by[10] = SH_C3[1] * xz;      bz[10] = SH_C3[1] * xy;
+                b[11] = SH_C3[2] * y * (4.f * zz - xx - yy);
+                bx[11] = SH_C3[2] * -2.f * xy;       by[11] = SH_C3[2] * (-3.f * yy + 4.f * zz - xx);
+                bz[11] = SH_C3[2] * 4.f * 2.f * yz;
+                b[12] = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                bx[12] = SH_C3[3] * -3.f * 2.f * xz; by[12] = SH_C3[3] * -3.f * 2.f * yz;
+                bz[12] = SH_C3[3] * 3.f * (2.f * zz - xx - yy);
+                b[13] = SH_C3[4] * x * (4.f * zz - xx - yy);
+                bx[13] = SH_C3[4] * (-3.f * xx + 4.f * zz - yy); by[13] = SH_C3[4] * -2.f * xy;
+                bz[13] = SH_C3[4] * 4.f * 2.f * xz;
+                b[14] = SH_C3[5] * z * (xx - yy);
+                bx[14] = SH_C3[5] * 2.f * xz;        by[14] = SH_C3[5] * -2.f * yz; bz[14] = SH_C3[5] * (xx - yy);
+                b[15] = SH_C3[6] * x * (xx - 3.f * yy);
+                bx[15] = SH_C3[6] * 3.f * (xx - yy); by[15] = SH_C3[6] * -3.f * 2.f * xy;
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        dsh[3 * k] = basis[k] * dL_dRGB.x; dsh[3 * k + 1] = basis[k] * dL_dRGB.y; dsh[3 * k + 2] = basis[k] * dL_dRGB.z;
-    }
-    return { dot(dRGBdx, dL_dRGB), dot(dRGBdy, dL_dRGB), dot(dRGBdz, dL_dRGB) };
 }
 
-// Backward of ONE visible Gaussian.
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+// sum within each 16-lane row; every lane of the row ends with the row total
+__device__ __forceinline__ float row_sum(float v)
+{
+    v += dpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += dpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += dpp<0x141>(v);           // row_half_mirror
+    v += dpp<0x140>(v);           // row_mirror
+    return v;
+}
+
+// Backward of ONE visible Gaussian, everything except the spherical-harmonics rows (those are handled 16 lanes per
+// Gaussian by the caller, which passes the resulting dL/d(view direction) in `dL_ddir` when `have_sh`).
 __device__ __forceinline__ void
 gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict__ means3D, const float* __restrict__ scales,
-            const float* __restrict__ rotations, const float* __restrict__ shs,
-            const float* __restrict__ cov3D_precomp,
-            const uint8_t* __restrict__ clamped, const float4 g0, const float4 g1, const float4 g2,
+            const float* __restrict__ rotations, const bool have_sh, const V3 dL_ddir,
+            const float* __restrict__ cov3D_precomp, const float4 g0, const float4 g1, const float4 g2,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
-            float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+            float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
             uint32_t accum_mask)
 {
     const size_t i = (size_t)idx;
     const float* __restrict__ V = vp.view;
     const float* __restrict__ Pm = vp.proj;
-    const int shrow = vp.M * 3;
 
     float o_m2d[3] = { 0, 0, 0 }, o_col[3] = { 0, 0, 0 }, o_m3d[3] = { 0, 0, 0 }, o_scale[3] = { 0, 0, 0 };
     float o_conic[4] = { 0, 0, 0, 0 }, o_rot[4] = { 0, 0, 0, 0 };
     float o_cov[6] = { 0, 0, 0, 0, 0, 0 };
     float o_op = 0.f;
-    float dsh[48];
-#pragma unroll
-    for (int k = 0; k < 48; k++) dsh[k] = 0.f;
 
     {
         const float gmx = g0.x, gmy = g0.y;                 // dL/dmean2D
@@ -243,23 +232,10 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
         o_m3d[1] += (Pm[4] * m_w - Pm[7] * mul1) * gmx + (Pm[5] * m_w - Pm[7] * mul2) * gmy;
         o_m3d[2] += (Pm[8] * m_w - Pm[11] * mul1) * gmx + (Pm[9] * m_w - Pm[11] * mul2) * gmy;
 
-        // ---- SH backward (backward.cu:20-139) ----
-        if (shs != nullptr) {
-            const V3 dir_orig = { mx - vp.campos[0], my - vp.campos[1], mz - vp.campos[2] };
-            const float len = sqrtf(dot(dir_orig, dir_orig));
-            const V3 dir = { dir_orig.x / len, dir_orig.y / len, dir_orig.z / len };
-            const uint8_t cb = clamped[idx];
-            const V3 dL_dRGB = { (cb & 1) ? 0.f : o_col[0], (cb & 2) ? 0.f : o_col[1], (cb & 4) ? 0.f : o_col[2] };
-            const float* sh_row = shs + i * shrow;
-            V3 dL_ddir;
-            switch (vp.D) {
-                case 0: dL_ddir = sh_backward<0>(sh_row, dir, dL_dRGB, dsh); break;
-                case 1: dL_ddir = sh_backward<1>(sh_row, dir, dL_dRGB, dsh); break;
-                case 2: dL_ddir = sh_backward<2>(sh_row, dir, dL_dRGB, dsh); break;
-                default: dL_ddir = sh_backward<3>(sh_row, dir, dL_dRGB, dsh); break;
-            }
+        // ---- view-direction gradient of the SH colour -> mean (backward.cu:128-138) ----
+        if (have_sh) {
+            const V3 v = { mx - vp.campos[0], my - vp.campos[1], mz - vp.campos[2] }, dv = dL_ddir;
             // dnormvdv (auxiliary.h:107-117)
-            const V3 v = dir_orig, dv = dL_ddir;
             const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
             const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
             o_m3d[0] += ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
@@ -318,36 +294,20 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
         *pr = v;
     }
 #undef LR_OUT
-    if (dL_dsh != nullptr && shrow > 0) {
-        float* dst = dL_dsh + i * shrow;
-        const int nk = 3 * (vp.D + 1) * (vp.D + 1);            // only the active bands are non-zero
-        const bool acc = (accum_mask >> ACC_SH) & 1u;
-        if ((shrow & 3) == 0 && (reinterpret_cast<uintptr_t>(dL_dsh) & 15) == 0) {
-#pragma unroll
-            for (int q = 0; q < 12; q++) {
-                if (4 * q < nk) {
-                    float4 v = make_float4(dsh[4 * q], dsh[4 * q + 1], dsh[4 * q + 2], dsh[4 * q + 3]);
-                    float4* pq = reinterpret_cast<float4*>(dst) + q;
-                    if (acc) { const float4 o = *pq; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-                    *pq = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 48; k++)
-                if (k < nk) dst[k] = acc ? dst[k] + dsh[k] : dsh[k];
-        }
-    }
 }
 
-// Each single-wave workgroup owns GB_CHUNK consecutive Gaussians: it compacts the visible ones (radii > 0 and at
-// least one instance) into LDS with ballots and then runs the heavy per-Gaussian backward densely over that list.  With few visible Gaussians
-// (camera paths see ~10 % of a scene) a thread-per-Gaussian launch would run the full 200-VGPR body in
-// every wave for a handful of live lanes; here the body runs once per CHUNK/64 as many Gaussians, index
-// order (and with it coalescing of the row reads/writes) is preserved, and no global atomics are needed.
-constexpr int GB_CHUNK = 256;        // Gaussians per workgroup
-constexpr int GB_THREADS = 64;       // ONE wave per workgroup: the heavy body needs ~200 VGPRs (2 waves/SIMD), so small
-                                     // single-wave groups keep 4x more independent chunks in flight than 256-thread ones
+// Persistent single-wave workgroups walk the index-ordered list of emitting Gaussians that the forward's compaction
+// left in the geometry buffer (vis_list, hdr->num_compact entries), 64 Gaussians per round, rounds dealt round-robin.
+// Only Gaussians that own at least one tile instance do any work or touch memory (camera paths see ~10-20 % of a
+// scene; a thread-per-Gaussian launch would run the heavy body in every wave for a handful of live lanes), index
+// order -- and with it the locality of the row reads/writes -- is preserved, and no global atomics are needed.
+// A round is a chain of dependent memory operations (list -> slots -> rows -> LDS -> SH rows), i.e. latency bound:
+// what matters is many independent rounds in flight, hence single-wave groups and a register budget of 128.
+constexpr int GB_THREADS = 64;
+#ifndef LR_GB_WAVES
+#define LR_GB_WAVES 3
+#endif
+constexpr int GB_MAX_GROUPS = 256 * 4 * LR_GB_WAVES;      // CUs x SIMDs x resident waves
 
 __device__ __forceinline__ void add4(float4& a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 __device__ __forceinline__ float wave_sum(float v)
@@ -357,10 +317,10 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-__global__ void __launch_bounds__(GB_THREADS)
+__global__ void __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(LR_GB_WAVES, 8)))
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
-            const float* __restrict__ cov3D_precomp, const int* __restrict__ radii,
+            const float* __restrict__ cov3D_precomp, const uint32_t* __restrict__ vis_list,
             const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
             const uint32_t* __restrict__ goff, const char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
@@ -369,21 +329,13 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             uint32_t accum_mask)
 {
     constexpr uint32_t SERIAL_MAX = 24;      // instances summed by the owning lane; more -> whole wave helps
-    __shared__ uint32_t s_list[GB_CHUNK];
-    const int base = blockIdx.x * GB_CHUNK;
+    constexpr int BST = 17;                  // LDS row stride (floats) of the per-Gaussian basis rows: odd -> no conflicts
+    __shared__ uint32_t s_idx[GB_THREADS];
+    __shared__ float s_b[4][32 * BST];           // basis, d/dx, d/dy, d/dz of 32 Gaussians (half a round)
+    __shared__ float s_rgb[3][GB_THREADS];       // dL/dRGB after the clamp mask
+    __shared__ float s_ddir[3][GB_THREADS];      // dL/d(view direction)
     const int lane = threadIdx.x;
-    uint32_t s_count = 0;                                   // wave-uniform running count
-#pragma unroll
-    for (int r = 0; r < GB_CHUNK / GB_THREADS; r++) {
-        const int idx = base + r * GB_THREADS + lane;
-        // a visible Gaussian whose tiles were all culled has an all-zero gradient: nothing to do for it
-        const bool vis = idx < vp.P && radii[idx] > 0 && tiles_touched[idx] != 0;
-        const uint64_t m = __ballot(vis);
-        if (vis) s_list[s_count + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
-        s_count += (uint32_t)__popcll(m);
-    }
-    __syncthreads();
-    const uint32_t n = s_count;
+    const uint32_t n = hdr->num_compact;
     if (n == 0) return;
     // per-instance partial sums written by k_render_bwd (48-byte slots, contiguous per Gaussian in emission
     // order); slots at or beyond num_sorted were never built (async-mode overflow) and are ignored
@@ -391,18 +343,28 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         reinterpret_cast<const float4*>(bin_base + bin_layout((long long)hdr->bin_bound).inst_grad);
     const uint32_t n_slots = hdr->num_sorted;
 
-    for (uint32_t t0 = 0; t0 < n; t0 += GB_THREADS) {
+    for (uint32_t t0 = blockIdx.x * GB_THREADS; t0 < n; t0 += gridDim.x * GB_THREADS) {
         const uint32_t t = t0 + threadIdx.x;
         const bool live = t < n;
-        const int idx = live ? (int)s_list[t] : 0;
+        const int idx = live ? (int)vis_list[t] : 0;
+        s_idx[lane] = (uint32_t)idx;
         const uint32_t tt = live ? tiles_touched[idx] : 0u;
         const uint32_t off = live ? goff[idx] : 0u;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
-        if (tt <= SERIAL_MAX) {
-            for (uint32_t j = 0; j < tt; j++) {
-                if (off + j >= n_slots) break;
-                const float4* slot = inst_grad + 3 * (size_t)(off + j);
-                add4(g0, slot[0]); add4(g1, slot[1]); add4(g2, slot[2]);
+        if (tt <= SERIAL_MAX && off < n_slots) {
+            // four slots per step with independent loads (a one-slot loop pays one memory latency per instance)
+            const uint32_t cnt = min(tt, n_slots - off);
+            const float4* first = inst_grad + 3 * (size_t)off;
+            for (uint32_t j = 0; j < cnt; j += 4) {
+                float4 a[4][3];
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    const float4* slot = first + 3 * (size_t)min(j + q, cnt - 1);
+                    a[q][0] = slot[0]; a[q][1] = slot[1]; a[q][2] = slot[2];
+                }
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++)
+                    if (j + q < cnt) { add4(g0, a[q][0]); add4(g1, a[q][1]); add4(g2, a[q][2]); }
             }
         }
         uint64_t big = __ballot(tt > SERIAL_MAX);
@@ -421,10 +383,93 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             p2.x = wave_sum(p2.x);
             if (lane == src) { g0 = p0; g1 = p1; g2 = p2; }
         }
+        // ---- spherical harmonics: rows are 3*M floats per Gaussian.  One lane per Gaussian would make every
+        // load/store instruction touch 64 different rows (64 cache lines for 16 useful bytes each, and the working
+        // set of a wave overflows the L1); instead each lane computes the 16 basis values and their direction
+        // derivatives of ITS Gaussian into LDS, and then 16 LANES share one Gaussian, lane k owning coefficient k:
+        // a wave reads/updates 4 complete rows per step with fully used cache lines.
+        V3 dL_ddir = { 0.f, 0.f, 0.f };
+        const bool have_sh = shs != nullptr && dL_dsh != nullptr;
+        if (have_sh) {
+            const int k = lane & 15, sub = lane >> 4;
+            const int K = (vp.D + 1) * (vp.D + 1);
+            const size_t shrow = (size_t)vp.M * 3;
+            const bool acc = (accum_mask >> ACC_SH) & 1u;
+            const int n_here = (int)min((uint32_t)GB_THREADS, n - t0);
+            if (live) {
+                const uint8_t cb = clamped[idx];
+                s_rgb[0][lane] = (cb & 1) ? 0.f : g1.z;
+                s_rgb[1][lane] = (cb & 2) ? 0.f : g1.w;
+                s_rgb[2][lane] = (cb & 4) ? 0.f : g2.x;
+            }
+            // two half rounds of 32 Gaussians keep the LDS footprint (and with it the occupancy limit) small
+            for (int half = 0; half < 2; half++) {
+                if (half * 32 >= n_here) break;
+                if (live && (lane >> 5) == half) {
+                    const size_t i = (size_t)idx;
+                    const V3 d0 = { means3D[3 * i] - vp.campos[0], means3D[3 * i + 1] - vp.campos[1], means3D[3 * i + 2] - vp.campos[2] };
+                    const float len = sqrtf(dot(d0, d0));
+                    const V3 dir = { d0.x / len, d0.y / len, d0.z / len };
+                    float b[16], bx[16], by[16], bz[16];
+                    switch (vp.D) {
+                        case 0: sh_basis<0>(dir, b, bx, by, bz); break;
+                        case 1: sh_basis<1>(dir, b, bx, by, bz); break;
+                        case 2: sh_basis<2>(dir, b, bx, by, bz); break;
+                        default: sh_basis<3>(dir, b, bx, by, bz); break;
+                    }
+                    const int o = (lane & 31) * BST;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        s_b[0][o + q] = b[q]; s_b[1][o + q] = bx[q]; s_b[2][o + q] = by[q]; s_b[3][o + q] = bz[q];
+                    }
+                }
+                __syncthreads();
+                // four steps (16 Gaussians) at a time: all row loads are issued before the first store, which the
+                // compiler cannot do across steps by itself (the accumulate loads may alias the previous stores)
+                for (int it0 = 0; it0 < 8; it0 += 4) {
+                    if (half * 32 + it0 * 4 >= n_here) break;
+                    float sv[4][3], dv[4][3];
+                    size_t rowv[4];
+                    bool onv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int gl = (it0 + q) * 4 + sub, g = half * 32 + gl;
+                        onv[q] = g < n_here && k < K;
+                        rowv[q] = (size_t)s_idx[onv[q] ? g : 0] * shrow + 3 * (onv[q] ? k : 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float* sp = shs + rowv[q];
+                        sv[q][0] = sp[0]; sv[q][1] = sp[1]; sv[q][2] = sp[2];
+                        if (acc) { const float* dp = dL_dsh + rowv[q]; dv[q][0] = dp[0]; dv[q][1] = dp[1]; dv[q][2] = dp[2]; }
+                        else { dv[q][0] = 0.f; dv[q][1] = 0.f; dv[q][2] = 0.f; }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int gl = (it0 + q) * 4 + sub, g = half * 32 + gl;
+                        const int gs = onv[q] ? g : 0, gls = onv[q] ? gl : 0, ks = onv[q] ? k : 0;
+                        const float r0 = s_rgb[0][gs], r1 = s_rgb[1][gs], r2 = s_rgb[2][gs];
+                        const float bk = s_b[0][gls * BST + ks];
+                        if (onv[q]) {
+                            float* dp = dL_dsh + rowv[q];
+                            dp[0] = dv[q][0] + bk * r0; dp[1] = dv[q][1] + bk * r1; dp[2] = dv[q][2] + bk * r2;
+                        }
+                        const float sd = onv[q] ? sv[q][0] * r0 + sv[q][1] * r1 + sv[q][2] * r2 : 0.f;
+                        const float px = row_sum(s_b[1][gls * BST + ks] * sd);
+                        const float py = row_sum(s_b[2][gls * BST + ks] * sd);
+                        const float pz = row_sum(s_b[3][gls * BST + ks] * sd);
+                        if (k == 0 && g < n_here) { s_ddir[0][g] = px; s_ddir[1][g] = py; s_ddir[2][g] = pz; }
+                    }
+                }
+                __syncthreads();
+            }
+            if (live) dL_ddir = { s_ddir[0][lane], s_ddir[1][lane], s_ddir[2][lane] };
+        }
         if (live)
-            gauss_backward_one(idx, vp, means3D, scales, rotations, shs, cov3D_precomp, clamped, g0, g1, g2,
-                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale,
+            gauss_backward_one(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
+                               dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale,
                                dL_drot, accum_mask);
+        __syncthreads();                     // the LDS planes are rewritten by the next round
     }
 }
 
@@ -478,7 +523,7 @@ void launch_zero_outputs(float* const* ptrs, const unsigned long long* nfloats, 
 
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const int* radii, const uint8_t* clamped, const uint32_t* tiles_touched,
+                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* tiles_touched,
                       const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
@@ -486,8 +531,9 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
 {
     (void)colors_precomp;
     if (vp.P <= 0) return;
-    hipLaunchKernelGGL(k_gauss_bwd, dim3((vp.P + GB_CHUNK - 1) / GB_CHUNK), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
-                       cov3D_precomp, radii, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
+    const int groups = std::min((vp.P + GB_THREADS - 1) / GB_THREADS, GB_MAX_GROUPS);
+    hipLaunchKernelGGL(k_gauss_bwd, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
+                       cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
                        dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
 }
 
