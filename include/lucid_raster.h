@@ -161,6 +161,79 @@ int lr_backward(int P, int D, int M, int R,
                 void* stream);
 
 /*
+ * Raw-parameter fast path (no counterpart in the reference's native code).
+ * The reference's Python caller materialises the activated parameters for every view before calling the
+ * rasterizer -- exp(scaling), normalize(rotation), sigmoid(opacity) and torch.cat(features_dc, features_rest)
+ * (R/scene/gaussian_model.py:97-117, R/gaussian_renderer/__init__.py:53-80): a 192 B/Gaussian copy plus four
+ * elementwise kernels forward, and their autograd counterparts backward.  These two entry points take the STORED
+ * GaussianModel tensors instead and apply the activations (forward) and their derivatives (backward) inside the
+ * per-Gaussian kernels:
+ *   xyz [P,3]; features_dc [P,1,3]; features_rest [P,M-1,3] (NULL iff M == 1); opacity_raw [P,1] (pre-sigmoid);
+ *   scaling_raw [P,3] (pre-exp); rotation_raw [P,4] (pre-normalisation, torch.nn.functional.normalize eps 1e-12).
+ * M = 1 + number of rest coefficients; D as in lr_forward.  colors_precomp / cov3D_precomp / prefiltered do not
+ * exist in this mode.  Everything else (scratch buffers, binning_capacity, stream, return value, errors) is as in
+ * lr_forward / lr_backward; the scratch buffers of a raw forward must be used with lr_backward_raw.
+ * Gradients are with respect to the stored tensors: dL_dopacity_raw [P], dL_dxyz [P,3], dL_dfeatures_dc [P,3],
+ * dL_dfeatures_rest [P,M-1,3], dL_dscaling_raw [P,3], dL_drotation_raw [P,4]; dL_dmean2D [P,3] as in lr_backward.
+ * accumulate_mask uses the LR_ACC_* bits of the corresponding lr_backward outputs (LR_ACC_SH covers both feature
+ * tensors).
+ */
+int lr_forward_raw(lr_alloc_fn geom_alloc, void* geom_user,
+                   lr_alloc_fn binning_alloc, void* binning_user,
+                   lr_alloc_fn img_alloc, void* img_user,
+                   int P, int D, int M,
+                   const float* background,
+                   int width, int height,
+                   const float* xyz,
+                   const float* features_dc,
+                   const float* features_rest,
+                   const float* opacity_raw,
+                   const float* scaling_raw,
+                   float scale_modifier,
+                   const float* rotation_raw,
+                   const float* viewmatrix,
+                   const float* projmatrix,
+                   const float* cam_pos,
+                   float tan_fovx, float tan_fovy,
+                   float* out_color,
+                   float* out_depth,
+                   int* radii,
+                   int debug,
+                   long long binning_capacity,
+                   void* stream);
+
+int lr_backward_raw(int P, int D, int M, int R,
+                    const float* background,
+                    int width, int height,
+                    const float* xyz,
+                    const float* features_dc,
+                    const float* features_rest,
+                    const float* opacity_raw,
+                    const float* scaling_raw,
+                    float scale_modifier,
+                    const float* rotation_raw,
+                    const float* viewmatrix,
+                    const float* projmatrix,
+                    const float* campos,
+                    float tan_fovx, float tan_fovy,
+                    const int* radii,
+                    char* geom_buffer,
+                    char* binning_buffer,
+                    char* image_buffer,
+                    const float* dL_dpix,
+                    float* dL_dmean2D,
+                    float* dL_dopacity_raw,
+                    float* dL_dxyz,
+                    float* dL_dfeatures_dc,
+                    float* dL_dfeatures_rest,
+                    float* dL_dscaling_raw,
+                    float* dL_drotation_raw,
+                    int debug,
+                    long long binning_capacity,
+                    unsigned int accumulate_mask,
+                    void* stream);
+
+/*
  * Multi-view step (new; the reference renders one view per Python iteration, luciddreamer.py:291-304).
  * Runs lr_forward + lr_backward for n_views views of ONE parameter set and ACCUMULATES the gradients into the
  * acc_* buffers (same shapes as lr_backward's outputs; acc_color / acc_cov3D / acc_sh / acc_scale / acc_rot may be

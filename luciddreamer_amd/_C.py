@@ -209,6 +209,113 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     return (r("means2D"), r("colors"), r("opacity"), r("means3D"), r("cov3D"), r("sh"), r("scales"), r("rotations"))
 
 
+def rasterize_gaussians_raw(background, xyz, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                            scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                            degree, campos, debug, *, binning_capacity=0):
+    """Forward on the STORED GaussianModel tensors (lr_forward_raw): exp / normalize / sigmoid and
+    the features_dc|features_rest split are handled inside the kernels.  Returns the tuple of rasterize_gaussians."""
+    if xyz.ndimension() != 2 or xyz.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_device(xyz, "xyz")
+    dev = xyz.device
+    L = _lib.lib()
+    P, H, W = int(xyz.size(0)), int(image_height), int(image_width)
+    out_color = torch.empty((NUM_CHANNELS, H, W), dtype=torch.float32, device=dev)
+    out_depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    if P == 0:
+        empty = torch.empty((0,), dtype=torch.uint8, device=dev)
+        return 0, out_color.zero_(), out_depth.zero_(), radii, empty, empty.clone(), empty.clone()
+    if features_dc.numel() != 3 * P:
+        raise RuntimeError("features_dc must have dimensions (num_points, 1, 3)")
+    M = 1 + (int(features_rest.size(1)) if (features_rest is not None and features_rest.numel() != 0) else 0)
+    t = [_f32(v, dev, n) for v, n in ((background, "background"), (xyz, "xyz"), (features_dc, "features_dc"),
+                                      (features_rest, "features_rest"), (opacity_raw, "opacity"),
+                                      (scaling_raw, "scaling"), (rotation_raw, "rotation"), (viewmatrix, "viewmatrix"),
+                                      (projmatrix, "projmatrix"), (campos, "campos"))]
+    bg, xyz_c, dc, rest, op, sc, rot, view, proj, cam = t
+    call = {"device": dev, "bufs": [None, None, None]}
+    _tls.call = call
+    try:
+        with _on_device(dev):
+            rc = L.lr_forward_raw(_ALLOC, 0, _ALLOC, 1, _ALLOC, 2, P, int(degree), M, _ptr(bg), W, H, _ptr(xyz_c), _ptr(dc),
+                                  _ptr(rest), _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(view), _ptr(proj),
+                                  _ptr(cam), float(tan_fovx), float(tan_fovy), out_color.data_ptr(), out_depth.data_ptr(),
+                                  radii.data_ptr(), int(bool(debug)), int(binning_capacity), _stream(dev))
+    finally:
+        _tls.call = None
+    if rc < 0 and rc != _lib.LR_NUM_RENDERED_ON_DEVICE:
+        _lib.raise_for(rc, "rasterize_gaussians_raw")
+    geom, binning, img = call["bufs"]
+    if binning is None:
+        binning = torch.empty((0,), dtype=torch.uint8, device=dev)
+    return rc, out_color, out_depth, radii, geom, binning, img
+
+
+# accumulate_into names of the raw backward -> LR_ACC_* bit (features_dc and features_rest share LR_ACC_SH)
+RAW_ACC_BITS = {"means2D": 0, "opacity": 2, "xyz": 4, "features": 6, "scaling": 7, "rotation": 8}
+
+
+def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, features_rest, opacity_raw, scaling_raw,
+                                     rotation_raw, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
+                                     dL_dout_color, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *,
+                                     binning_capacity=0, accumulate_into=None):
+    """Gradients w.r.t. the stored tensors: (means2D, xyz, features_dc, features_rest, opacity, scaling, rotation).
+    accumulate_into: {"means2D","xyz","opacity","scaling","rotation": tensor, "features": (dc_grad, rest_grad)} adds
+    in place (slot returned as None)."""
+    _require_device(xyz, "xyz")
+    dev = xyz.device
+    L = _lib.lib()
+    P = int(xyz.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    nrest = int(features_rest.size(1)) if (features_rest is not None and features_rest.numel() != 0) else 0
+    M = 1 + nrest
+    opt = dict(dtype=torch.float32, device=dev)
+    acc = accumulate_into or {}
+    mask = 0
+    shapes = {"means2D": (P, 3), "xyz": (P, 3), "opacity": (P, 1), "scaling": (P, 3), "rotation": (P, 4)}
+    outs = {}
+
+    def usable(t, n):
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.device != dev or t.numel() != n:
+            raise RuntimeError(f"accumulate_into tensors must be contiguous float32 of the gradient's size on {dev}")
+        return t
+    for name, shape in shapes.items():
+        t = acc.get(name)
+        if t is not None:
+            outs[name] = usable(t, shape[0] * shape[1])
+            mask |= 1 << RAW_ACC_BITS[name]
+        else:
+            outs[name] = torch.empty(shape, **opt)
+    fa = acc.get("features")
+    if fa is not None:
+        g_dc, g_rest = usable(fa[0], 3 * P), (usable(fa[1], 3 * nrest * P) if nrest else None)
+        mask |= 1 << RAW_ACC_BITS["features"]
+    else:
+        g_dc = torch.empty((P, 1, 3), **opt)
+        g_rest = torch.empty((P, nrest, 3), **opt)
+    if P != 0:
+        t = [_f32(v, dev, n) for v, n in ((background, "background"), (xyz, "xyz"), (features_dc, "features_dc"),
+                                          (features_rest, "features_rest"), (opacity_raw, "opacity"),
+                                          (scaling_raw, "scaling"), (rotation_raw, "rotation"), (viewmatrix, "viewmatrix"),
+                                          (projmatrix, "projmatrix"), (campos, "campos"), (dL_dout_color, "dL_dout_color"))]
+        bg, xyz_c, dc, rest, op, sc, rot, view, proj, cam, g_color = t
+        radii_c = radii.contiguous()
+        with _on_device(dev):
+            rc = L.lr_backward_raw(P, int(degree), M, int(R), _ptr(bg), W, H, _ptr(xyz_c), _ptr(dc), _ptr(rest), _ptr(op),
+                                   _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(view), _ptr(proj), _ptr(cam),
+                                   float(tan_fovx), float(tan_fovy), radii_c.data_ptr(), geomBuffer.data_ptr(),
+                                   binningBuffer.data_ptr(), imageBuffer.data_ptr(), _ptr(g_color),
+                                   outs["means2D"].data_ptr(), outs["opacity"].data_ptr(), outs["xyz"].data_ptr(),
+                                   g_dc.data_ptr(), _ptr(g_rest) if nrest else None, outs["scaling"].data_ptr(),
+                                   outs["rotation"].data_ptr(), int(bool(debug)), int(binning_capacity), mask, _stream(dev))
+        if rc < 0:
+            _lib.raise_for(rc, "rasterize_gaussians_raw_backward")
+    r = lambda name: None if acc.get(name) is not None else outs[name]
+    f = (None, None) if fa is not None else (g_dc, g_rest)
+    return (r("means2D"), r("xyz"), f[0], f[1], r("opacity"), r("scaling"), r("rotation"))
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     _require_device(means3D, "means3D")
     dev = means3D.device

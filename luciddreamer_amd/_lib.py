@@ -24,7 +24,7 @@ _lib = None
 _lock = threading.Lock()
 
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
-           "lr_backward", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
+           "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check")
 
@@ -66,6 +66,19 @@ def lib():
                                   vp, vp, vp, vp, vp,                            # geom binning img dL_dpix dL_ddepth
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp,            # 9 gradient outputs
                                   ci, ll, ctypes.c_uint, vp]                     # debug capacity accumulate_mask stream
+        L.lr_forward_raw.restype = ci
+        L.lr_forward_raw.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp,  # allocators
+                                     ci, ci, ci, vp, ci, ci,                     # P D M bg W H
+                                     vp, vp, vp, vp, vp, cf, vp,                 # xyz f_dc f_rest opacity scaling mod rotation
+                                     vp, vp, vp, cf, cf,                         # view proj campos tanx tany
+                                     vp, vp, vp, ci, ll, vp]                     # out_color out_depth radii debug capacity stream
+        L.lr_backward_raw.restype = ci
+        L.lr_backward_raw.argtypes = [ci, ci, ci, ci, vp, ci, ci,                # P D M R bg W H
+                                      vp, vp, vp, vp, vp, cf, vp,                # xyz f_dc f_rest opacity scaling mod rotation
+                                      vp, vp, vp, cf, cf, vp,                    # view proj campos tanx tany radii
+                                      vp, vp, vp, vp,                            # geom binning img dL_dpix
+                                      vp, vp, vp, vp, vp, vp, vp,                # 7 gradient outputs
+                                      ci, ll, ctypes.c_uint, vp]                 # debug capacity accumulate_mask stream
         L.lr_mark_visible.restype = ci
         L.lr_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
         L.lr_check.restype = ci

@@ -88,13 +88,16 @@ size_t lr_geom_bytes(int P) { return lr::geom_layout(P).total; }
 size_t lr_img_bytes(int width, int height) { return lr::img_layout(width, height).total; }
 size_t lr_binning_bytes(long long R) { return lr::bin_layout(R).total; }
 
-int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_alloc, void* binning_user,
+// raw-parameter mode (lr_forward_raw / lr_backward_raw): see ViewParams in common.h
+struct RawArgs { const float* sh_rest; const float* opacity_raw; float* dL_dsh_rest; };
+
+static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_alloc, void* binning_user,
                lr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
                int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-               float* out_depth, int* radii, int debug, long long binning_capacity, void* stream_)
+               float* out_depth, int* radii, int debug, long long binning_capacity, void* stream_, const RawArgs* raw)
 {
     using namespace lr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
@@ -147,6 +150,7 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     vp.focal_x = width / (2.0f * tan_fovx);
     vp.scale_modifier = scale_modifier;
     vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
+    vp.raw = raw != nullptr; vp.sh_rest = raw ? raw->sh_rest : nullptr; vp.opacity_raw = nullptr; vp.dL_dsh_rest = nullptr;
 
     long long R_bound = 0;
     int num_rendered = 0;
@@ -249,6 +253,38 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_allo
     return num_rendered;
 }
 
+int lr_forward(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_alloc, void* binning_user,
+               lr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
+               int width, int height, const float* means3D, const float* shs, const float* colors_precomp,
+               const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+               const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+               const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+               float* out_depth, int* radii, int debug, long long binning_capacity, void* stream_)
+{
+    return forward_core(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width,
+                        height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, radii, debug,
+                        binning_capacity, stream_, nullptr);
+}
+
+int lr_forward_raw(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn binning_alloc, void* binning_user,
+                   lr_alloc_fn img_alloc, void* img_user, int P, int D, int M, const float* background,
+                   int width, int height, const float* xyz, const float* features_dc, const float* features_rest,
+                   const float* opacity_raw, const float* scaling_raw, float scale_modifier, const float* rotation_raw,
+                   const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                   float tan_fovy, float* out_color, float* out_depth, int* radii, int debug,
+                   long long binning_capacity, void* stream_)
+{
+    if (P > 0 && (!features_dc || !opacity_raw || !scaling_raw || !rotation_raw || (M > 1 && !features_rest)))
+        return fail(LR_ERR_INVALID_ARG, "raw mode needs features_dc, features_rest (M > 1), opacity, scaling and rotation");
+    if (M < 1) return fail(LR_ERR_INVALID_ARG, "raw mode: M = 1 + number of features_rest coefficients must be >= 1");
+    const RawArgs raw = { features_rest, opacity_raw, nullptr };
+    return forward_core(geom_alloc, geom_user, binning_alloc, binning_user, img_alloc, img_user, P, D, M, background, width,
+                        height, xyz, features_dc, nullptr, opacity_raw, scaling_raw, scale_modifier, rotation_raw, nullptr,
+                        viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, 0, out_color, out_depth, radii, debug,
+                        binning_capacity, stream_, &raw);
+}
+
 static int backward_core(int P, int D, int M, int R, const float* background, int width, int height,
                 const float* means3D, const float* shs, const float* colors_precomp, const float* scales,
                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
@@ -257,7 +293,8 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
                 const float* dL_dpix, const float* dL_depths, float* dL_dmean2D, float* dL_dconic,
                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                 float* dL_dscale, float* dL_drot, int debug, long long binning_capacity,
-                unsigned int accumulate_mask, void* stream_, hipEvent_t wait_before_accumulate)
+                unsigned int accumulate_mask, void* stream_, hipEvent_t wait_before_accumulate,
+                const RawArgs* raw = nullptr)
 {
     using namespace lr;
     (void)dL_depths;   // ignored, as in the reference (backward.cu:457-464, 539-554 commented out)
@@ -297,6 +334,10 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
     vp.focal_x = width / (2.0f * tan_fovx);
     vp.scale_modifier = scale_modifier;
     vp.W = width; vp.H = height; vp.gx = gx; vp.gy = gy; vp.P = P; vp.D = D; vp.M = M;
+    vp.raw = raw != nullptr;
+    vp.sh_rest = raw ? raw->sh_rest : nullptr;
+    vp.opacity_raw = raw ? raw->opacity_raw : nullptr;
+    vp.dL_dsh_rest = raw ? raw->dL_dsh_rest : nullptr;
 
     { ProfScope ps(ST_RENDER_BWD, s);
     launch_render_bwd(width, height, gx, gy, ranges, point_list, rec, background, final_T, n_contrib, dL_dpix,
@@ -308,10 +349,15 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
         ProfScope ps(ST_OUT_ZERO, s);
         const unsigned long long Pn = (unsigned long long)P;
         float* ptrs[9] = { dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot };
-        const unsigned long long nf[9] = { 3 * Pn, 4 * Pn, Pn, 3 * Pn, 3 * Pn, 6 * Pn, (unsigned long long)M * 3 * Pn, 3 * Pn, 4 * Pn };
-        float* zp[9]; unsigned long long zn[9]; int zc = 0;
+        // raw mode: dL_dsh is the features_dc gradient [P,3]; the features_rest gradient is a second tensor
+        const unsigned long long nsh = raw ? 3 * Pn : (unsigned long long)M * 3 * Pn;
+        const unsigned long long nf[9] = { 3 * Pn, 4 * Pn, Pn, 3 * Pn, 3 * Pn, 6 * Pn, nsh, 3 * Pn, 4 * Pn };
+        float* zp[10]; unsigned long long zn[10]; int zc = 0;
         for (int k = 0; k < 9; k++)
             if (ptrs[k] != nullptr && !((accumulate_mask >> k) & 1u)) { zp[zc] = ptrs[k]; zn[zc] = nf[k]; zc++; }
+        if (raw && raw->dL_dsh_rest != nullptr && M > 1 && !((accumulate_mask >> ACC_SH) & 1u) && zc < 9) {
+            zp[zc] = raw->dL_dsh_rest; zn[zc] = (unsigned long long)(M - 1) * 3 * Pn; zc++;
+        }
         launch_zero_outputs(zp, zn, zc, s);
     }
     { ProfScope ps(ST_GAUSS_BWD, s);
@@ -339,6 +385,27 @@ int lr_backward(int P, int D, int M, int R, const float* background, int width, 
                          geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_depths, dL_dmean2D, dL_dconic,
                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug,
                          binning_capacity, accumulate_mask, stream_, nullptr);
+}
+
+int lr_backward_raw(int P, int D, int M, int R, const float* background, int width, int height,
+                    const float* xyz, const float* features_dc, const float* features_rest, const float* opacity_raw,
+                    const float* scaling_raw, float scale_modifier, const float* rotation_raw,
+                    const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                    float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                    const float* dL_dpix, float* dL_dmean2D, float* dL_dopacity_raw, float* dL_dxyz,
+                    float* dL_dfeatures_dc, float* dL_dfeatures_rest, float* dL_dscaling_raw, float* dL_drotation_raw,
+                    int debug, long long binning_capacity, unsigned int accumulate_mask, void* stream_)
+{
+    if (P > 0 && (!features_dc || !opacity_raw || !scaling_raw || !rotation_raw || (M > 1 && !features_rest)))
+        return fail(LR_ERR_INVALID_ARG, "raw mode needs features_dc, features_rest (M > 1), opacity, scaling and rotation");
+    if (P > 0 && (!dL_dfeatures_dc || (M > 1 && !dL_dfeatures_rest)))
+        return fail(LR_ERR_INVALID_ARG, "raw mode needs dL_dfeatures_dc and dL_dfeatures_rest");
+    const RawArgs raw = { features_rest, opacity_raw, dL_dfeatures_rest };
+    return backward_core(P, D, M, R, background, width, height, xyz, features_dc, nullptr, scaling_raw, scale_modifier,
+                         rotation_raw, nullptr, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer,
+                         binning_buffer, image_buffer, dL_dpix, nullptr, dL_dmean2D, nullptr, dL_dopacity_raw, nullptr,
+                         dL_dxyz, nullptr, dL_dfeatures_dc, dL_dscaling_raw, dL_drotation_raw, debug, binning_capacity,
+                         accumulate_mask, stream_, nullptr, &raw);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -184,7 +184,24 @@ struct ViewParams {
     const float* campos;    // device, 3 floats
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int W, H, gx, gy, P, D, M;
+    // raw-parameter mode (lr_forward_raw / lr_backward_raw): scales, rotations and opacities are the STORED
+    // GaussianModel parameters (pre exp / normalize / sigmoid, R/scene/gaussian_model.py:97-117) and the SH
+    // coefficients come as two arrays, `shs` = features_dc [P,1,3] and `sh_rest` = features_rest [P,M-1,3]
+    // (no torch.cat copy).  The activations and their derivatives are applied inside the per-Gaussian kernels.
+    int raw;
+    const float* sh_rest;
+    const float* opacity_raw;     // backward only (sigmoid derivative)
+    float* dL_dsh_rest;           // backward only
 };
+
+// activations of the raw mode; one definition so that forward and backward recompute identical values
+__device__ __forceinline__ float act_scale(float s) { return expf(s); }
+__device__ __forceinline__ float act_opacity(float o) { return 1.0f / (1.0f + expf(-o)); }
+// torch.nn.functional.normalize: q / max(||q||_2, 1e-12)
+__device__ __forceinline__ float act_quat_inv_norm(float r, float x, float y, float z)
+{
+    return 1.0f / fmaxf(sqrtf(r * r + x * x + y * y + z * z), 1e-12f);
+}
 
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,

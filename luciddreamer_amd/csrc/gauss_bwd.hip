@@ -114,6 +114,9 @@ __device__ __forceinline__ float row_sum(float v)
 
 // Backward of ONE visible Gaussian, everything except the spherical-harmonics rows (those are handled 16 lanes per
 // Gaussian by the caller, which passes the resulting dL/d(view direction) in `dL_ddir` when `have_sh`).
+// RAW (lr_backward_raw) is a template parameter, not a run-time branch: with `if (vp.raw)` blocks in this function
+// ROCm 7.2 hipcc produced wrong dL/dcov3D in the NON-raw path (verified on hardware by removing either block).
+template <bool RAW>
 __device__ __forceinline__ void
 gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const bool have_sh, const V3 dL_ddir,
@@ -145,15 +148,22 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
         // ---- recompute cov3D (forward.cu:118-152) ----
         float c3[6];
         float sx = 0, sy = 0, sz = 0, qr = 0, qx = 0, qy = 0, qz = 0;
+        float raw_s[3] = { 1.f, 1.f, 1.f }, raw_inv = 1.f;      // raw mode: activated scales, 1/max(|q|, eps)
         M3 Rm = {}, Mm = {};
         if (cov3D_precomp != nullptr) {
 #pragma unroll
             for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * i + k];
         } else {
-            sx = vp.scale_modifier * scales[3 * i]; sy = vp.scale_modifier * scales[3 * i + 1];
-            sz = vp.scale_modifier * scales[3 * i + 2];
+            sx = scales[3 * i]; sy = scales[3 * i + 1]; sz = scales[3 * i + 2];
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
             qr = q.x; qx = q.y; qy = q.z; qz = q.w;
+            if (RAW) {
+                sx = act_scale(sx); sy = act_scale(sy); sz = act_scale(sz);
+                raw_s[0] = sx; raw_s[1] = sy; raw_s[2] = sz;
+                raw_inv = act_quat_inv_norm(qr, qx, qy, qz);
+                qr *= raw_inv; qx *= raw_inv; qy *= raw_inv; qz *= raw_inv;
+            }
+            sx *= vp.scale_modifier; sy *= vp.scale_modifier; sz *= vp.scale_modifier;
             M3 S = { { { sx, 0, 0 }, { 0, sy, 0 }, { 0, 0, sz } } };
             Rm = { { { 1.f - 2.f * (qy * qy + qz * qz), 2.f * (qx * qy - qr * qz), 2.f * (qx * qz + qr * qy) },
                      { 2.f * (qx * qy + qr * qz), 1.f - 2.f * (qx * qx + qz * qz), 2.f * (qy * qz - qr * qx) },
@@ -267,6 +277,17 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
             o_rot[2] = 2 * qx * (Q(1, 0) + Q(0, 1)) + 2 * qr * (Q(2, 0) - Q(0, 2)) + 2 * qz * (Q(1, 2) + Q(2, 1)) - 4 * qy * (Q(2, 2) + Q(0, 0));
             o_rot[3] = 2 * qr * (Q(0, 1) - Q(1, 0)) + 2 * qx * (Q(2, 0) + Q(0, 2)) + 2 * qy * (Q(1, 2) + Q(2, 1)) - 4 * qz * (Q(1, 1) + Q(0, 0));
 #undef Q
+            if (RAW) {
+                // through exp: d/ds_raw = d/ds * exp(s_raw); through q = r/|r|: (g - q (q.g)) / |r|
+                o_scale[0] *= raw_s[0]; o_scale[1] *= raw_s[1]; o_scale[2] *= raw_s[2];
+                const float qg = qr * o_rot[0] + qx * o_rot[1] + qy * o_rot[2] + qz * o_rot[3];
+                o_rot[0] = (o_rot[0] - qr * qg) * raw_inv; o_rot[1] = (o_rot[1] - qx * qg) * raw_inv;
+                o_rot[2] = (o_rot[2] - qy * qg) * raw_inv; o_rot[3] = (o_rot[3] - qz * qg) * raw_inv;
+            }
+        }
+        if (RAW) {
+            const float o = act_opacity(vp.opacity_raw[i]);
+            o_op *= o * (1.0f - o);
         }
     }
 
@@ -317,6 +338,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
+template <bool RAW>
 __global__ void __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(LR_GB_WAVES, 8)))
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
@@ -435,13 +457,17 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                     for (int q = 0; q < 4; q++) {
                         const int gl = (it0 + q) * 4 + sub, g = half * 32 + gl;
                         onv[q] = g < n_here && k < K;
-                        rowv[q] = (size_t)s_idx[onv[q] ? g : 0] * shrow + 3 * (onv[q] ? k : 0);
+                        const size_t gi = (size_t)s_idx[onv[q] ? g : 0];
+                        const int kk = onv[q] ? k : 0;
+                        // raw mode: coefficient 0 lives in features_dc [P,3], the others in features_rest [P,M-1,3]
+                        rowv[q] = !RAW ? gi * shrow + 3 * kk : (kk == 0 ? gi * 3 : gi * (shrow - 3) + 3 * (kk - 1));
                     }
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const float* sp = shs + rowv[q];
+                        const bool in_rest = RAW && onv[q] && k != 0;      // idle lanes re-read row 0 of features_dc
+                        const float* sp = (in_rest ? vp.sh_rest : shs) + rowv[q];
                         sv[q][0] = sp[0]; sv[q][1] = sp[1]; sv[q][2] = sp[2];
-                        if (acc) { const float* dp = dL_dsh + rowv[q]; dv[q][0] = dp[0]; dv[q][1] = dp[1]; dv[q][2] = dp[2]; }
+                        if (acc) { const float* dp = (in_rest ? vp.dL_dsh_rest : dL_dsh) + rowv[q]; dv[q][0] = dp[0]; dv[q][1] = dp[1]; dv[q][2] = dp[2]; }
                         else { dv[q][0] = 0.f; dv[q][1] = 0.f; dv[q][2] = 0.f; }
                     }
 #pragma unroll
@@ -451,7 +477,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                         const float r0 = s_rgb[0][gs], r1 = s_rgb[1][gs], r2 = s_rgb[2][gs];
                         const float bk = s_b[0][gls * BST + ks];
                         if (onv[q]) {
-                            float* dp = dL_dsh + rowv[q];
+                            float* dp = ((RAW && k != 0) ? vp.dL_dsh_rest : dL_dsh) + rowv[q];   // onv[q] holds here
                             dp[0] = dv[q][0] + bk * r0; dp[1] = dv[q][1] + bk * r1; dp[2] = dv[q][2] + bk * r2;
                         }
                         const float sd = onv[q] ? sv[q][0] * r0 + sv[q][1] * r1 + sv[q][2] * r2 : 0.f;
@@ -466,7 +492,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             if (live) dL_ddir = { s_ddir[0][lane], s_ddir[1][lane], s_ddir[2][lane] };
         }
         if (live)
-            gauss_backward_one(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
+            gauss_backward_one<RAW>(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
                                dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale,
                                dL_drot, accum_mask);
         __syncthreads();                     // the LDS planes are rewritten by the next round
@@ -532,9 +558,14 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
     (void)colors_precomp;
     if (vp.P <= 0) return;
     const int groups = std::min((vp.P + GB_THREADS - 1) / GB_THREADS, GB_MAX_GROUPS);
-    hipLaunchKernelGGL(k_gauss_bwd, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
-                       cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor,
-                       dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
+    if (vp.raw)
+        hipLaunchKernelGGL(k_gauss_bwd<true>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
+                           cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
+    else
+        hipLaunchKernelGGL(k_gauss_bwd<false>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
+                           cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
 }
 
 }  // namespace lr

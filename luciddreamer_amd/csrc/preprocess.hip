@@ -79,11 +79,24 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, size_t id
     for (int k = 0; k < K; k++) { sh[k].x = f[3 * k]; sh[k].y = f[3 * k + 1]; sh[k].z = f[3 * k + 2]; }
 }
 
+// raw mode: coefficient 0 from features_dc [P,3], coefficients 1.. from features_rest [P,M-1,3]
+template <int K>
+__device__ __forceinline__ void load_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, size_t idx, int M,
+                                              V3 (&sh)[16])
+{
+    sh[0].x = dc[3 * idx]; sh[0].y = dc[3 * idx + 1]; sh[0].z = dc[3 * idx + 2];
+    const float* base = rest + idx * (size_t)(M - 1) * 3;
+#pragma unroll
+    for (int k = 1; k < K; k++) { sh[k].x = base[3 * (k - 1)]; sh[k].y = base[3 * (k - 1) + 1]; sh[k].z = base[3 * (k - 1) + 2]; }
+}
+
 template <int DEG>
-__device__ __forceinline__ V3 eval_sh(const float* __restrict__ shs, size_t idx, int M, V3 dir, uint8_t& clamp_bits)
+__device__ __forceinline__ V3 eval_sh(const float* __restrict__ shs, const float* __restrict__ sh_rest, size_t idx, int M, V3 dir,
+                                      uint8_t& clamp_bits)
 {
     V3 sh[16];
-    load_sh<(DEG + 1) * (DEG + 1)>(shs, idx, M, sh);
+    if (sh_rest != nullptr) load_sh_split<(DEG + 1) * (DEG + 1)>(shs, sh_rest, idx, M, sh);
+    else load_sh<(DEG + 1) * (DEG + 1)>(shs, idx, M, sh);
     V3 res = { SH_C0 * sh[0].x, SH_C0 * sh[0].y, SH_C0 * sh[0].z };
     if (DEG > 0) {
         float x = dir.x, y = dir.y, z = dir.z;
@@ -133,30 +146,52 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
              uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tiles_ref,
              uint32_t* __restrict__ depth_key, GeomHeader* hdr, uint32_t binning_capacity)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = idx < vp.P;
-    if (idx == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
+    // Phase 1, one thread per Gaussian: the near-plane test (auxiliary.h:152-162).  Survivors are compacted, in index
+    // order, into LDS; phase 2 runs the ~600-instruction projection / covariance / SH body on dense lanes only (on a
+    // camera path about half of a scene is behind the camera, so half of the waves of a block skip it entirely).
+    __shared__ uint32_t s_list[256];
+    __shared__ uint32_t s_wcnt[4];
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
     const float* __restrict__ V = vp.view;
     const float* __restrict__ Pm = vp.proj;
+    {
+        const bool in_range = gid < vp.P;
+        const size_t li = in_range ? (size_t)gid : 0;
+        const float vz1 = V[2] * means3D[3 * li] + V[6] * means3D[3 * li + 1] + V[10] * means3D[3 * li + 2] + V[14];
+        const bool pass = in_range && !(vz1 <= 0.2f);
+        if (in_range && !pass) {
+            if (prefiltered) hdr->prefilter_trap = 1;
+            radii[gid] = 0; tiles_touched[gid] = 0; tiles_ref[gid] = 0; depth_key[gid] = 0xFFFFFFFFu;
+        }
+        const uint64_t m = __ballot(pass);
+        const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (l == 0) s_wcnt[w] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0;
+        for (int i = 0; i < w; i++) before += s_wcnt[i];
+        if (pass) s_list[before + __popcll(m & ((1ull << l) - 1ull))] = (uint32_t)gid;
+        __syncthreads();
+    }
+    const uint32_t n_pass = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    if ((threadIdx.x & ~63u) >= n_pass) return;             // whole wave has nothing to do
+    const bool live = threadIdx.x < n_pass;
+    const int idx = live ? (int)s_list[threadIdx.x] : 0;
 
     int radius_out = 0;
     uint32_t tiles_out = 0;               // tile instances this Gaussian will emit (after exact tile culling)
     uint32_t area_ref = 0;                // the reference's tiles_touched (rectangle area)
     uint32_t key_out = 0xFFFFFFFFu;       // culled Gaussians sort to the end and emit nothing
 
-    const size_t li = live ? (size_t)idx : 0;
+    const size_t li = (size_t)idx;
     const float px_w = means3D[3 * li], py_w = means3D[3 * li + 1], pz_w = means3D[3 * li + 2];
-    // view-space point (auxiliary.h:58-66) and the near cull z <= 0.2 (auxiliary.h:152-162)
+    // view-space point (auxiliary.h:58-66)
     const float vx = V[0] * px_w + V[4] * py_w + V[8] * pz_w + V[12];
     const float vy = V[1] * px_w + V[5] * py_w + V[9] * pz_w + V[13];
     const float vz = V[2] * px_w + V[6] * py_w + V[10] * pz_w + V[14];
 
     do {
         if (!live) break;
-        if (vz <= 0.2f) {
-            if (prefiltered) hdr->prefilter_trap = 1;
-            break;
-        }
         // clip-space projection (forward.cu:196-200)
         const float hx = Pm[0] * px_w + Pm[4] * py_w + Pm[8] * pz_w + Pm[12];
         const float hy = Pm[1] * px_w + Pm[5] * py_w + Pm[9] * pz_w + Pm[13];
@@ -170,9 +205,14 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
 #pragma unroll
             for (int i = 0; i < 6; i++) c3[i] = cov3D_precomp[6 * (size_t)idx + i];
         } else {
-            const float sx = scales[3 * (size_t)idx], sy = scales[3 * (size_t)idx + 1], sz = scales[3 * (size_t)idx + 2];
+            float sx = scales[3 * (size_t)idx], sy = scales[3 * (size_t)idx + 1], sz = scales[3 * (size_t)idx + 2];
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
-            const float r = q.x, x = q.y, y = q.z, z = q.w;
+            float r = q.x, x = q.y, y = q.z, z = q.w;
+            if (vp.raw) {
+                sx = act_scale(sx); sy = act_scale(sy); sz = act_scale(sz);
+                const float inv = act_quat_inv_norm(r, x, y, z);
+                r *= inv; x *= inv; y *= inv; z *= inv;
+            }
             M3 S = { { { vp.scale_modifier * sx, 0, 0 }, { 0, vp.scale_modifier * sy, 0 }, { 0, 0, vp.scale_modifier * sz } } };
             M3 R = { { { 1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y) },
                        { 2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x) },
@@ -224,17 +264,17 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
             const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
             dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
             switch (vp.D) {
-                case 0: rgb = eval_sh<0>(shs, idx, vp.M, dir, cbits); break;
-                case 1: rgb = eval_sh<1>(shs, idx, vp.M, dir, cbits); break;
-                case 2: rgb = eval_sh<2>(shs, idx, vp.M, dir, cbits); break;
-                default: rgb = eval_sh<3>(shs, idx, vp.M, dir, cbits); break;
+                case 0: rgb = eval_sh<0>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                case 1: rgb = eval_sh<1>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                case 2: rgb = eval_sh<2>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                default: rgb = eval_sh<3>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
             }
         }
         clamped[idx] = cbits;
 
         GaussRec g;
         g.x = pix; g.y = piy; g.ca = con_a; g.cb = con_b;
-        g.cc = con_c; g.opacity = opacities[idx]; g.r = rgb.x; g.g = rgb.y;
+        g.cc = con_c; g.opacity = vp.raw ? act_opacity(opacities[idx]) : opacities[idx]; g.r = rgb.x; g.g = rgb.y;
         g.b = rgb.z; g.depth = vz; g.qmax = cull_qmax(g.opacity); g.pad1 = 0.f;
         float4* dst = reinterpret_cast<float4*>(rec + idx);
         dst[0] = make_float4(g.x, g.y, g.ca, g.cb);

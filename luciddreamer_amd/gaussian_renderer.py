@@ -12,7 +12,7 @@ from types import SimpleNamespace
 
 import torch
 
-from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
 
 DEFAULT_OPT = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
 
@@ -63,6 +63,33 @@ def render(viewpoint_camera, pc, opt=DEFAULT_OPT, bg_color=None, scaling_modifie
     rendered_image, radii, depth = rasterizer(
         means3D=xyz, means2D=screenspace_points, shs=shs, colors_precomp=colors_precomp,
         opacities=pc.get_opacity, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    if render_only:
+        return {"render": rendered_image, "depth": depth}
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii, "depth": depth}
+
+
+def render_raw(viewpoint_camera, pc, opt=DEFAULT_OPT, bg_color=None, scaling_modifier=1.0, render_only=False):
+    """render() for the common training configuration (SH colours, scale/rotation covariance), reading the STORED
+    parameters of `pc` (`_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation`,
+    /root/reference/scene/gaussian_model.py:47-52) instead of the activated getters: the activations and the
+    dc|rest concatenation happen inside the rasterizer kernels.  Same return dict as render()."""
+    xyz = pc._xyz
+    if bg_color is None:
+        bg_color = torch.zeros(3, dtype=torch.float32, device=xyz.device)
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    rs = GaussianRasterizationSettings(
+        image_height=int(viewpoint_camera.image_height), image_width=int(viewpoint_camera.image_width),
+        tanfovx=math.tan(viewpoint_camera.FoVx * 0.5), tanfovy=math.tan(viewpoint_camera.FoVy * 0.5),
+        bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=viewpoint_camera.world_view_transform,
+        projmatrix=viewpoint_camera.full_proj_transform, sh_degree=pc.active_sh_degree,
+        campos=viewpoint_camera.camera_center, prefiltered=False, debug=bool(getattr(opt, "debug", False)))
+    rendered_image, radii, depth = rasterize_gaussians_raw(xyz, screenspace_points, pc._features_dc, pc._features_rest,
+                                                           pc._opacity, pc._scaling, pc._rotation, rs)
     if render_only:
         return {"render": rendered_image, "depth": depth}
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,

@@ -103,6 +103,59 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
                                      cov3Ds_precomp, raster_settings)
 
 
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Autograd op over the STORED GaussianModel tensors: one forward and one backward call replace
+    exp / normalize / sigmoid / cat and their autograd nodes (R/scene/gaussian_model.py:97-117)."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
+        rs = raster_settings
+        capacity = config.capacity_for(xyz, rs)
+        num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians_raw(
+            rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug,
+            binning_capacity=capacity)
+        config.note_forward(xyz, rs, num_rendered, geom, capacity)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.binning_capacity = capacity
+        ctx.leaf_inputs = dict(xyz=xyz, means2D=means2D, features_dc=features_dc, features_rest=features_rest,
+                               opacity=opacity, scaling=scaling, rotation=rotation) \
+            if config.fused_grad_accumulation() else None
+        ctx.save_for_backward(xyz, features_dc, features_rest, opacity, scaling, rotation, radii, geom, binning, img)
+        return color, radii, depth
+
+    @staticmethod
+    def backward(ctx, grad_out_color, grad_radii, grad_depth):
+        rs = ctx.raster_settings
+        xyz, features_dc, features_rest, opacity, scaling, rotation, radii, geom, binning, img = ctx.saved_tensors
+        if grad_out_color is None:
+            grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=xyz.device)
+        accumulate_into = None
+        if ctx.leaf_inputs is not None:
+            def leaf_grad(t):
+                g = t.grad if (t.is_leaf and t.requires_grad and t.numel() != 0) else None
+                ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == xyz.device
+                return g if ok else None
+            li = ctx.leaf_inputs
+            accumulate_into = {k: leaf_grad(li[k]) for k in ("xyz", "means2D", "opacity", "scaling", "rotation")}
+            g_dc, g_rest = leaf_grad(li["features_dc"]), leaf_grad(li["features_rest"])
+            if g_dc is not None and (g_rest is not None or features_rest.numel() == 0):
+                accumulate_into["features"] = (g_dc, g_rest)
+        g = _C.rasterize_gaussians_raw_backward(
+            rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+            binning, img, rs.debug, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into)
+        g_means2D, g_xyz, g_dc, g_rest, g_op, g_sc, g_rot = g
+        return g_xyz, g_means2D, g_dc, g_rest, g_op, g_sc, g_rot, None
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
+    """(color, radii, depth) from the stored GaussianModel parameters (pre-activation), see _RasterizeGaussiansRaw."""
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
+                                        raster_settings)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
