@@ -260,6 +260,24 @@ int lr_views_accumulate(int n_views, const float* const* viewmatrices, const flo
 int lr_views_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
                    void* stream);
 
+/*
+ * Fused photometric loss of the training loop:
+ *     loss = (1 - lambda) * mean|image - gt| + lambda * (1 - mean(SSIM_map(image, gt)))
+ * replacing l1_loss + ssim of R/utils/loss.py:18-69 as composed in R/luciddreamer.py:301-304 (11x11 window = outer
+ * product of a normalised Gaussian, sigma 1.5; zero padding 5; C1 = 0.01^2, C2 = 0.03^2; mean over all C*H*W).
+ * image, gt: [C,H,W] float32, contiguous (a batch [B,C,H,W] is passed as channels = B*C).
+ *   lr_l1_dssim_forward : out_loss3 (device, 3 floats) = {loss, l1, ssim}; fills `workspace` (device,
+ *                         lr_loss_workspace_bytes) with what the backward needs.  No host synchronisation.
+ *   lr_l1_dssim_backward: dL_dimage [C,H,W] = upstream * d loss / d image, from the workspace of the forward on the
+ *                         same inputs; `upstream` is a device scalar (autograd's grad_output) or NULL for 1.
+ * Deterministic (no atomics).  Return 0 or a negative LR_ERR_*.
+ */
+size_t lr_loss_workspace_bytes(int channels, int height, int width);
+int lr_l1_dssim_forward(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                        float* out_loss3, void* workspace, size_t workspace_bytes, void* stream);
+int lr_l1_dssim_backward(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                         const float* upstream, const void* workspace, float* dL_dimage, void* stream);
+
 /* present[P] (1 byte each) = view-space z > 0.2.  Returns 0 or a negative LR_ERR_*. */
 int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream);

@@ -26,7 +26,8 @@ _lock = threading.Lock()
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
            "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
-           "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check")
+           "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
+           "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward")
 
 
 def lib():
@@ -98,6 +99,12 @@ def lib():
                                           vp, ctypes.c_size_t, ll, ci, vp]       # workspace, bytes, capacity, n_streams, stream
         L.lr_views_check.restype = ci
         L.lr_views_check.argtypes = [vp, ci, ci, ci, ll, ci, vp]
+        L.lr_loss_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_loss_workspace_bytes.argtypes = [ci, ci, ci]
+        L.lr_l1_dssim_forward.restype = ci
+        L.lr_l1_dssim_forward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, ctypes.c_size_t, vp]
+        L.lr_l1_dssim_backward.restype = ci
+        L.lr_l1_dssim_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
         L.lr_profile_enable.restype = ci
         L.lr_profile_enable.argtypes = [ci]
         L.lr_profile_stage_name.restype = ctypes.c_char_p

@@ -28,6 +28,7 @@ SOURCES = {
     "render_bwd.hip": [],
     "gauss_bwd.hip": [],
     "knn.hip": [],
+    "loss.hip": [],
     "api.hip": [],
 }
 

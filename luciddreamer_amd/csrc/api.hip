@@ -547,6 +547,37 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
     return 0;
 }
 
+size_t lr_loss_workspace_bytes(int channels, int height, int width)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return 0;
+    return lr::loss_workspace_bytes(channels, height, width);
+}
+
+int lr_l1_dssim_forward(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                        float* out_loss3, void* workspace, size_t workspace_bytes, void* stream_)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return fail(LR_ERR_INVALID_ARG, "channels, height, width must be positive");
+    if (!image || !gt || !out_loss3 || !workspace) return fail(LR_ERR_INVALID_ARG, "image/gt/out_loss3/workspace are required");
+    if (workspace_bytes < lr::loss_workspace_bytes(channels, height, width))
+        return fail(LR_ERR_INVALID_ARG, "loss workspace too small (lr_loss_workspace_bytes)");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    lr::launch_loss_forward(channels, height, width, image, gt, lambda_dssim, out_loss3, static_cast<char*>(workspace), s);
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int lr_l1_dssim_backward(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
+                         const float* upstream, const void* workspace, float* dL_dimage, void* stream_)
+{
+    if (channels <= 0 || height <= 0 || width <= 0) return fail(LR_ERR_INVALID_ARG, "channels, height, width must be positive");
+    if (!image || !gt || !workspace || !dL_dimage) return fail(LR_ERR_INVALID_ARG, "image/gt/workspace/dL_dimage are required");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    lr::launch_loss_backward(channels, height, width, image, gt, lambda_dssim, upstream, static_cast<const char*>(workspace),
+                             dL_dimage, s);
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
                     unsigned char* present, void* stream_)
 {

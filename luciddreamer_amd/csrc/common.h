@@ -246,6 +246,12 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, hipStream_t s);
+// fused L1 + DSSIM loss (loss.hip)
+size_t loss_workspace_bytes(int C, int H, int W);
+void launch_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda, float* out3, char* ws,
+                         hipStream_t s);
+void launch_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda, const float* upstream,
+                          const char* ws, float* grad, hipStream_t s);
 // bit positions of lr_backward's accumulate_mask (LR_ACC_* in lucid_raster.h)
 enum { ACC_MEAN2D = 0, ACC_CONIC = 1, ACC_OPACITY = 2, ACC_COLOR = 3, ACC_MEAN3D = 4, ACC_COV3D = 5, ACC_SH = 6,
        ACC_SCALE = 7, ACC_ROT = 8 };

@@ -1,0 +1,263 @@
+// loss.hip -- fused L1 + DSSIM photometric loss and its gradient for gfx950.
+//
+// Replaces, for the training loop's loss (R/luciddreamer.py:301-304)
+//     loss = (1 - lambda) * l1_loss(image, gt) + lambda * (1 - ssim(image, gt))
+// the reference's Python composition (R/utils/loss.py:18-69): five grouped 11x11 F.conv2d (121 taps each, the 2-D
+// window is the outer product of a normalised 1-D Gaussian, sigma 1.5, zero padding 5), a dozen elementwise
+// kernels, two reductions, and the autograd replay of all of it.  Here:
+//   k_ssim_fwd : one pass over the image pair.  A 256-thread workgroup owns a 32x32 tile of one channel, stages
+//                the 42x42 halo region of both images in LDS, runs the five window sums SEPARABLY (11 + 11 taps,
+//                four adjacent outputs per thread per pass so that the sliding window re-uses LDS reads), forms the
+//                SSIM value and the three partial derivatives dS/d(conv I), dS/d(conv I^2), dS/d(conv I*G) per
+//                pixel, writes those three maps, and reduces sum(S) and sum|I-G| per workgroup (fixed order).
+//   k_loss_final: sums the per-workgroup partials in a fixed order (double) -> {loss, l1, ssim}.
+//   k_ssim_bwd : the adjoint of a symmetric zero-padded window sum is the same window sum, so
+//                dL/dI(q) = -lambda/n * [ W*D1 + 2 I(q) W*D2 + G(q) W*D3 ](q) + (1-lambda)/n * sign(I-G)(q),
+//                again separable through LDS, times the upstream scalar (device pointer, no host sync).
+// HBM-bound by construction: ~60 B per pixel-channel over both passes; no atomics, deterministic.
+#include "common.h"
+#include <cmath>
+
+namespace lr {
+
+namespace {
+
+constexpr int LT = 32;                 // tile edge (outputs)
+constexpr int HALO = 5;                // window 11
+constexpr int LR_IN = LT + 2 * HALO;   // 42
+constexpr int LTHREADS = 256;
+
+struct Win { float w[11]; };
+
+// gaussian(11, 1.5) of R/utils/loss.py:26-28: exp in double, cast to float32, normalised in float32
+Win make_window()
+{
+    Win g;
+    float v[11], sum = 0.f;
+    for (int x = 0; x < 11; x++) { v[x] = (float)std::exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5)); sum += v[x]; }
+    for (int x = 0; x < 11; x++) g.w[x] = v[x] / sum;
+    return g;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* s_tmp)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_tmp[w] = v;
+    __syncthreads();
+    return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
+}
+
+__global__ void __launch_bounds__(LTHREADS)
+k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restrict__ img, const float* __restrict__ gt,
+           float* __restrict__ D1, float* __restrict__ D2, float* __restrict__ D3, float2* __restrict__ partials)
+{
+    __shared__ float s_i[LR_IN][LR_IN + 1];
+    __shared__ float s_g[LR_IN][LR_IN + 1];
+    __shared__ float s_h[5][LR_IN][LT + 1];       // horizontal sums of I, G, I^2, G^2, I*G
+    __shared__ float s_tmp[4];
+
+    const int tile = blockIdx.x % (tiles_x * tiles_y), ch = blockIdx.x / (tiles_x * tiles_y);
+    const int x0 = (tile % tiles_x) * LT, y0 = (tile / tiles_x) * LT;
+    const size_t plane = (size_t)ch * H * W;
+    const int tid = threadIdx.x;
+
+    float l1_part = 0.f;
+    for (int p = tid; p < LR_IN * LR_IN; p += LTHREADS) {
+        const int ly = p / LR_IN, lx = p % LR_IN;
+        const int y = y0 + ly - HALO, x = x0 + lx - HALO;
+        float a = 0.f, b = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) { a = img[plane + (size_t)y * W + x]; b = gt[plane + (size_t)y * W + x]; }
+        s_i[ly][lx] = a; s_g[ly][lx] = b;
+        if (ly >= HALO && ly < HALO + LT && lx >= HALO && lx < HALO + LT) l1_part += fabsf(a - b);   // outside = 0
+    }
+    __syncthreads();
+
+    // horizontal pass: item = (row, group of 4 adjacent output columns)
+    for (int it = tid; it < LR_IN * (LT / 4); it += LTHREADS) {
+        const int row = it / (LT / 4), c0 = (it % (LT / 4)) * 4;
+        float a[14], b[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) { a[k] = s_i[row][c0 + k]; b[k] = s_g[row][c0 + k]; }
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const float w = win.w[k], u = a[o + k], v = b[o + k];
+                m1 += w * u; m2 += w * v; e11 += w * (u * u); e22 += w * (v * v); e12 += w * (u * v);
+            }
+            s_h[0][row][c0 + o] = m1; s_h[1][row][c0 + o] = m2; s_h[2][row][c0 + o] = e11;
+            s_h[3][row][c0 + o] = e22; s_h[4][row][c0 + o] = e12;
+        }
+    }
+    __syncthreads();
+
+    // vertical pass: thread = (column, group of 4 adjacent output rows)
+    const int col = tid % LT, r0 = (tid / LT) * 4;
+    float acc[5][4];
+#pragma unroll
+    for (int m = 0; m < 5; m++) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) v[k] = s_h[m][r0 + k][col];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) s += win.w[k] * v[o + k];
+            acc[m][o] = s;
+        }
+    }
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    float ssim_part = 0.f;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int y = y0 + r0 + o, x = x0 + col;
+        if (y < H && x < W) {
+            const float mu1 = acc[0][o], mu2 = acc[1][o];
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = acc[2][o] - mu1_sq, s2 = acc[3][o] - mu2_sq, s12 = acc[4][o] - mu12;
+            const float A1 = 2.f * mu12 + C1, A2 = 2.f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+            const float inv = 1.0f / (B1 * B2);
+            const float S = A1 * A2 * inv;
+            ssim_part += S;
+            // partial derivatives of S w.r.t. the window sums of I, I^2 and I*G (those of G, G^2 are not needed)
+            const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -S / B1, dB2 = -S / B2;
+            const size_t q = plane + (size_t)y * W + x;
+            D1[q] = dA1 * 2.f * mu2 + dB1 * 2.f * mu1 - dB2 * 2.f * mu1 - dA2 * 2.f * mu2;
+            D2[q] = dB2;
+            D3[q] = 2.f * dA2;
+        }
+    }
+    const float st = block_sum(ssim_part, s_tmp);
+    const float lt = block_sum(l1_part, s_tmp);
+    if (tid == 0) partials[blockIdx.x] = make_float2(st, lt);
+}
+
+__global__ void __launch_bounds__(LTHREADS)
+k_loss_final(int n_blocks, double n_elems, float lambda, const float2* __restrict__ partials, float* __restrict__ out)
+{
+    __shared__ double s_a[LTHREADS], s_b[LTHREADS];
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_blocks; i += LTHREADS) { const float2 p = partials[i]; a += p.x; b += p.y; }
+    s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
+    __syncthreads();
+    for (int off = LTHREADS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float ssim = (float)(s_a[0] / n_elems), l1 = (float)(s_b[0] / n_elems);
+        out[0] = (1.0f - lambda) * l1 + lambda * (1.0f - ssim);
+        out[1] = l1;
+        out[2] = ssim;
+    }
+}
+
+__global__ void __launch_bounds__(LTHREADS)
+k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float inv_n, const float* __restrict__ upstream,
+           const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ D1,
+           const float* __restrict__ D2, const float* __restrict__ D3, float* __restrict__ grad)
+{
+    __shared__ float s_d[3][LR_IN][LR_IN + 1];
+    __shared__ float s_h[3][LR_IN][LT + 1];
+    const int tile = blockIdx.x % (tiles_x * tiles_y), ch = blockIdx.x / (tiles_x * tiles_y);
+    const int x0 = (tile % tiles_x) * LT, y0 = (tile / tiles_x) * LT;
+    const size_t plane = (size_t)ch * H * W;
+    const int tid = threadIdx.x;
+
+    for (int p = tid; p < LR_IN * LR_IN; p += LTHREADS) {
+        const int ly = p / LR_IN, lx = p % LR_IN;
+        const int y = y0 + ly - HALO, x = x0 + lx - HALO;
+        float a = 0.f, b = 0.f, c = 0.f;
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            const size_t q = plane + (size_t)y * W + x;
+            a = D1[q]; b = D2[q]; c = D3[q];
+        }
+        s_d[0][ly][lx] = a; s_d[1][ly][lx] = b; s_d[2][ly][lx] = c;
+    }
+    __syncthreads();
+    for (int it = tid; it < LR_IN * (LT / 4); it += LTHREADS) {
+        const int row = it / (LT / 4), c0 = (it % (LT / 4)) * 4;
+#pragma unroll
+        for (int m = 0; m < 3; m++) {
+            float v[14];
+#pragma unroll
+            for (int k = 0; k < 14; k++) v[k] = s_d[m][row][c0 + k];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) s += win.w[k] * v[o + k];
+                s_h[m][row][c0 + o] = s;
+            }
+        }
+    }
+    __syncthreads();
+    const int col = tid % LT, r0 = (tid / LT) * 4;
+    float acc[3][4];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        float v[14];
+#pragma unroll
+        for (int k = 0; k < 14; k++) v[k] = s_h[m][r0 + k][col];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; k++) s += win.w[k] * v[o + k];
+            acc[m][o] = s;
+        }
+    }
+    const float up = upstream != nullptr ? upstream[0] : 1.0f;
+    const float k_ssim = -lambda * inv_n * up, k_l1 = (1.0f - lambda) * inv_n * up;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int y = y0 + r0 + o, x = x0 + col;
+        if (y < H && x < W) {
+            const size_t q = plane + (size_t)y * W + x;
+            const float a = img[q], b = gt[q];
+            const float d = a - b;
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);          // torch.abs backward: sign, 0 at 0
+            grad[q] = k_ssim * (acc[0][o] + 2.f * a * acc[1][o] + b * acc[2][o]) + k_l1 * sgn;
+        }
+    }
+}
+
+}  // namespace
+
+size_t loss_workspace_bytes(int C, int H, int W)
+{
+    const size_t n = (size_t)C * H * W;
+    const size_t blocks = (size_t)C * ((W + LT - 1) / LT) * ((H + LT - 1) / LT);
+    return align_up(3 * n * sizeof(float)) + align_up(blocks * sizeof(float2));
+}
+
+void launch_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda, float* out3, char* ws,
+                         hipStream_t s)
+{
+    static const Win win = make_window();
+    const size_t n = (size_t)C * H * W;
+    const int tx = (W + LT - 1) / LT, ty = (H + LT - 1) / LT;
+    const int blocks = C * tx * ty;
+    float* D = reinterpret_cast<float*>(ws);
+    float2* partials = reinterpret_cast<float2*>(ws + align_up(3 * n * sizeof(float)));
+    hipLaunchKernelGGL(k_ssim_fwd, dim3(blocks), dim3(LTHREADS), 0, s, H, W, tx, ty, win, img, gt, D, D + n, D + 2 * n, partials);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(LTHREADS), 0, s, blocks, (double)n, lambda, partials, out3);
+}
+
+void launch_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda, const float* upstream,
+                          const char* ws, float* grad, hipStream_t s)
+{
+    static const Win win = make_window();
+    const size_t n = (size_t)C * H * W;
+    const int tx = (W + LT - 1) / LT, ty = (H + LT - 1) / LT;
+    const float* D = reinterpret_cast<const float*>(ws);
+    hipLaunchKernelGGL(k_ssim_bwd, dim3(C * tx * ty), dim3(LTHREADS), 0, s, H, W, tx, ty, win, lambda, (float)(1.0 / (double)n),
+                       upstream, img, gt, D, D + n, D + 2 * n, grad);
+}
+
+}  // namespace lr

@@ -1,0 +1,71 @@
+"""Fused photometric loss of the training loop on the MI355X.
+
+    loss = l1_dssim_loss(image, gt, lambda_dssim)      # == (1-l)*l1_loss(image, gt) + l*(1 - ssim(image, gt))
+
+is what /root/reference/luciddreamer.py:301-304 computes with utils/loss.py's l1_loss (:18-19) and ssim (:37-69).
+`l1_loss` and `ssim` with the reference's names and meaning are provided as well.  One HIP kernel pass forward and one
+backward (luciddreamer_amd/csrc/loss.hip) through the C-ABI (lr_l1_dssim_forward / lr_l1_dssim_backward); no CPU or
+PyTorch fallback.  Gradients flow to `image` only (the target is data).
+"""
+import torch
+
+from . import _lib
+
+
+class _L1DSSIM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, lambda_dssim):
+        if not image.is_cuda or not gt.is_cuda:
+            raise RuntimeError("luciddreamer_amd.loss: image and gt must be on a HIP device (no CPU path)")
+        if image.shape != gt.shape or image.dim() < 2:
+            raise RuntimeError(f"image {tuple(image.shape)} and gt {tuple(gt.shape)} must have the same [..., H, W] shape")
+        if image.dtype != torch.float32 or gt.dtype != torch.float32:
+            raise RuntimeError("image and gt must be float32")
+        x, g = image.contiguous(), gt.contiguous()
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+        C = x.numel() // (H * W)
+        L = _lib.lib()
+        dev = x.device
+        out3 = torch.empty((3,), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), float(lambda_dssim), out3.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.raise_for(rc, "l1_dssim_loss")
+        ctx.save_for_backward(x, g, ws)
+        ctx.lam, ctx.dims, ctx.in_shape = float(lambda_dssim), (C, H, W), image.shape
+        ctx.parts = out3                      # {loss, l1, ssim}, device
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, g, ws = ctx.saved_tensors
+        C, H, W = ctx.dims
+        L = _lib.lib()
+        dev = x.device
+        up = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        grad = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = L.lr_l1_dssim_backward(C, H, W, x.data_ptr(), g.data_ptr(), ctx.lam, up.data_ptr(), ws.data_ptr(),
+                                        grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.raise_for(rc, "l1_dssim_loss backward")
+        return grad.view(ctx.in_shape), None, None
+
+
+def l1_dssim_loss(image, gt, lambda_dssim=0.2):
+    """(1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)); image, gt: [C,H,W] (or [B,C,H,W])."""
+    return _L1DSSIM.apply(image, gt, lambda_dssim)
+
+
+def l1_loss(network_output, gt):
+    """utils/loss.py:18-19."""
+    return _L1DSSIM.apply(network_output, gt, 0.0)
+
+
+def ssim(img1, img2, window_size=11, size_average=True):
+    """utils/loss.py:37-46 (window 11, averaged over everything -- the only configuration the training loop uses)."""
+    if window_size != 11 or not size_average:
+        raise NotImplementedError("fused ssim supports window_size=11, size_average=True")
+    return 1.0 - _L1DSSIM.apply(img1, img2, 1.0)
