@@ -261,6 +261,27 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
                    void* stream);
 
 /*
+ * Row surgery of the Gaussian parameter set.  The reference changes the number of Gaussians
+ * with boolean-mask indexing / torch.cat applied tensor by tensor to the six parameters and both Adam moments of
+ * each (R/scene/gaussian_model.py:273-340 prune_points, _prune_optimizer, cat_tensors_to_optimizer; :342-403
+ * densify_and_clone / densify_and_split / densify_and_prune).
+ *   lr_select_rows: for every i in [0,P) with mask[i] != 0, in increasing i, row i of each of the n_tensors source
+ *     tensors is copied to row (dst_row_offset + rank(i)) of its destination; rank(i) = number of selected rows
+ *     before i.  row_bytes[t] (multiple of 4) is the row size of tensor t; src/dst/row_bytes are HOST arrays of
+ *     n_tensors (<= 32) entries holding DEVICE pointers; dst may alias src only when dst_row_offset >= P (appending
+ *     behind the live rows of a capacity buffer); a compaction goes to the other half of a ping-pong buffer.  *out_count (device int) receives the number
+ *     of selected rows.  n_tensors == 0 only counts.  No host synchronisation.
+ *   lr_pack_ply_rows: builds the 17 + 3*(M-1) float vertex records written by GaussianModel.save_ply (:193-208:
+ *     x y z nx ny nz, f_dc_*, f_rest_* channel-major, opacity, scale_*, rot_*) in out_rows [P, 17+3(M-1)] (device).
+ */
+size_t lr_select_workspace_bytes(int P);
+int lr_select_rows(int P, const unsigned char* mask, int n_tensors, const void* const* src, void* const* dst,
+                   const unsigned* row_bytes, long long dst_row_offset, int* out_count, void* workspace,
+                   size_t workspace_bytes, void* stream);
+int lr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, const float* features_rest,
+                     const float* opacity, const float* scaling, const float* rotation, float* out_rows, void* stream);
+
+/*
  * Fused photometric loss of the training loop:
  *     loss = (1 - lambda) * mean|image - gt| + lambda * (1 - mean(SSIM_map(image, gt)))
  * replacing l1_loss + ssim of R/utils/loss.py:18-69 as composed in R/luciddreamer.py:301-304 (11x11 window = outer

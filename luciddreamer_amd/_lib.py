@@ -27,7 +27,8 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
-           "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward")
+           "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward",
+           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows")
 
 
 def lib():
@@ -105,6 +106,12 @@ def lib():
         L.lr_l1_dssim_forward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, ctypes.c_size_t, vp]
         L.lr_l1_dssim_backward.restype = ci
         L.lr_l1_dssim_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
+        L.lr_select_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_select_workspace_bytes.argtypes = [ci]
+        L.lr_select_rows.restype = ci
+        L.lr_select_rows.argtypes = [ci, vp, ci, vp, vp, vp, ll, vp, vp, ctypes.c_size_t, vp]
+        L.lr_pack_ply_rows.restype = ci
+        L.lr_pack_ply_rows.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
         L.lr_profile_enable.restype = ci
         L.lr_profile_enable.argtypes = [ci]
         L.lr_profile_stage_name.restype = ctypes.c_char_p

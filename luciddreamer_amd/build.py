@@ -29,6 +29,7 @@ SOURCES = {
     "gauss_bwd.hip": [],
     "knn.hip": [],
     "loss.hip": [],
+    "rows.hip": [],
     "api.hip": [],
 }
 

@@ -547,6 +547,46 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
     return 0;
 }
 
+size_t lr_select_workspace_bytes(int P) { return lr::select_workspace_bytes(P); }
+
+int lr_select_rows(int P, const unsigned char* mask, int n_tensors, const void* const* src, void* const* dst,
+                   const unsigned* row_bytes, long long dst_row_offset, int* out_count, void* workspace,
+                   size_t workspace_bytes, void* stream_)
+{
+    if (P < 0 || n_tensors < 0 || dst_row_offset < 0) return fail(LR_ERR_INVALID_ARG, "P, n_tensors, dst_row_offset must be >= 0");
+    if (!out_count || !workspace) return fail(LR_ERR_INVALID_ARG, "out_count and workspace are required");
+    if (workspace_bytes < lr::select_workspace_bytes(P)) return fail(LR_ERR_INVALID_ARG, "select workspace too small");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (P == 0) { LR_HIP_CHECK(hipMemsetAsync(out_count, 0, sizeof(int), s)); return 0; }
+    if (!mask || (n_tensors > 0 && (!src || !dst || !row_bytes))) return fail(LR_ERR_INVALID_ARG, "mask/src/dst/row_bytes are required");
+    for (int t = 0; t < n_tensors; t++) {
+        if (!src[t] || !dst[t]) return fail(LR_ERR_INVALID_ARG, "NULL tensor in lr_select_rows");
+        // appending behind the live rows of the same buffer is fine; compaction in place is not (rows would be
+        // overwritten before other workgroups have read them)
+        if (src[t] == dst[t] && dst_row_offset < P)
+            return fail(LR_ERR_INVALID_ARG, "lr_select_rows: dst may alias src only when dst_row_offset >= P");
+    }
+    const int rc = lr::launch_select_rows(P, mask, n_tensors, src, dst, row_bytes, dst_row_offset, out_count,
+                                          static_cast<char*>(workspace), s);
+    if (rc == -1) return fail(LR_ERR_INVALID_ARG, "at most 32 tensors per lr_select_rows call");
+    if (rc == -2) return fail(LR_ERR_INVALID_ARG, "row_bytes must be a positive multiple of 4");
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
+int lr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, const float* features_rest,
+                     const float* opacity, const float* scaling, const float* rotation, float* out_rows, void* stream_)
+{
+    if (P < 0 || M < 1) return fail(LR_ERR_INVALID_ARG, "P >= 0 and M >= 1 required");
+    if (P == 0) return 0;
+    if (!xyz || !features_dc || !opacity || !scaling || !rotation || !out_rows || (M > 1 && !features_rest))
+        return fail(LR_ERR_INVALID_ARG, "all parameter tensors and out_rows are required");
+    lr::launch_pack_ply(P, M - 1, xyz, features_dc, features_rest, opacity, scaling, rotation, out_rows,
+                        reinterpret_cast<hipStream_t>(stream_));
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 size_t lr_loss_workspace_bytes(int channels, int height, int width)
 {
     if (channels <= 0 || height <= 0 || width <= 0) return 0;

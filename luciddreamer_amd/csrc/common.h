@@ -246,6 +246,12 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, hipStream_t s);
+// row surgery of the parameter set (rows.hip)
+size_t select_workspace_bytes(int P);
+int launch_select_rows(int P, const uint8_t* mask, int n_tensors, const void* const* src, void* const* dst,
+                       const unsigned* row_bytes, long long dst_row_offset, int* out_count, char* ws, hipStream_t s);
+void launch_pack_ply(int P, int n_rest, const float* xyz, const float* f_dc, const float* f_rest, const float* opacity,
+                     const float* scaling, const float* rotation, float* out, hipStream_t s);
 // fused L1 + DSSIM loss (loss.hip)
 size_t loss_workspace_bytes(int C, int H, int W);
 void launch_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda, float* out3, char* ws,
