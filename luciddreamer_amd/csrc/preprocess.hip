@@ -137,6 +137,9 @@ __device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx
     maxy = min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
 }
 
+// RAW (lr_forward_raw) is a template parameter so that the standard path keeps its register budget (100 VGPRs,
+// 4 waves/SIMD; the split SH loader of raw mode needs 130)
+template <bool RAW>
 __global__ void __launch_bounds__(256)
 k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
              const float* __restrict__ rotations, const float* __restrict__ opacities,
@@ -208,7 +211,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
             float sx = scales[3 * (size_t)idx], sy = scales[3 * (size_t)idx + 1], sz = scales[3 * (size_t)idx + 2];
             const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
             float r = q.x, x = q.y, y = q.z, z = q.w;
-            if (vp.raw) {
+            if (RAW) {
                 sx = act_scale(sx); sy = act_scale(sy); sz = act_scale(sz);
                 const float inv = act_quat_inv_norm(r, x, y, z);
                 r *= inv; x *= inv; y *= inv; z *= inv;
@@ -264,17 +267,17 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
             const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
             dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
             switch (vp.D) {
-                case 0: rgb = eval_sh<0>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
-                case 1: rgb = eval_sh<1>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
-                case 2: rgb = eval_sh<2>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
-                default: rgb = eval_sh<3>(shs, vp.raw ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                case 0: rgb = eval_sh<0>(shs, RAW ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                case 1: rgb = eval_sh<1>(shs, RAW ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                case 2: rgb = eval_sh<2>(shs, RAW ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
+                default: rgb = eval_sh<3>(shs, RAW ? vp.sh_rest : nullptr, idx, vp.M, dir, cbits); break;
             }
         }
         clamped[idx] = cbits;
 
         GaussRec g;
         g.x = pix; g.y = piy; g.ca = con_a; g.cb = con_b;
-        g.cc = con_c; g.opacity = vp.raw ? act_opacity(opacities[idx]) : opacities[idx]; g.r = rgb.x; g.g = rgb.y;
+        g.cc = con_c; g.opacity = RAW ? act_opacity(opacities[idx]) : opacities[idx]; g.r = rgb.x; g.g = rgb.y;
         g.b = rgb.z; g.depth = vz; g.qmax = cull_qmax(g.opacity); g.pad1 = 0.f;
         float4* dst = reinterpret_cast<float4*>(rec + idx);
         dst[0] = make_float4(g.x, g.y, g.ca, g.cb);
@@ -325,9 +328,14 @@ void launch_preprocess(const ViewParams& vp, const float* means3D, const float* 
 {
     if (vp.P <= 0) return;
     dim3 grid((vp.P + 255) / 256), block(256);
-    hipLaunchKernelGGL(k_preprocess, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
-                       cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                       tiles_ref, depth_key, hdr, binning_capacity);
+    if (vp.raw)
+        hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
+                           cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
+                           tiles_ref, depth_key, hdr, binning_capacity);
+    else
+        hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
+                           cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
+                           tiles_ref, depth_key, hdr, binning_capacity);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
