@@ -223,17 +223,25 @@ def main():
     # runs for FETCH_SIZE and WRITE_SIZE; both in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for
     # 16-byte-per-lane reads on gfx950).  Only meaningful for the workload the counters were collected on.
     traffic = None
+    valu = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c3.json")
     if args.workload == "c3" and args.gaussians is None and os.path.exists(pmc_path):
         try:
             pmc = json.load(open(pmc_path)).get("k_" + dom, {})
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
+            if "SQ_INSTS_VALU" in pmc:
+                # the blend kernels are VALU-issue bound: wave-instructions per launch from the
+                # PMC pass over this launch's measured duration, against 256 CUs x 4 SIMDs x one VALU issue per 4
+                # cycles at 2.4 GHz (a v_fma_f32 micro-benchmark reaches 537 G/s)
+                ginst = pmc["SQ_INSTS_VALU"] / dom_avg_s / 1e9
+                valu = {"wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_ginst_s": round(ginst, 1),
+                        "peak_ginst_s": 614.4, "frac": round(ginst / 614.4, 4)}
         except (OSError, ValueError):
             traffic = None
     roofline = {
         "bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "valu_issue": valu,
         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
         "launches": dom_calls,
         "path_bytes_per_view": int(b_f + b_b),
