@@ -103,9 +103,14 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
              char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
 {
-    __shared__ float4 s_q0[BATCH];      // x, y, conic a, conic b
-    __shared__ float4 s_q1[BATCH];      // conic c, qmax, opacity, -
-    __shared__ float4 s_q2[BATCH];      // r, g, b, -
+    // Per-Gaussian constants are staged as DUPLICATED pairs {v, v}: the blend math is packed FP32 on 2-pixel vectors and a
+    // scalar operand that sits in an odd register (or must be broadcast) costs a v_mov per use in this VALU-issue-bound
+    // loop; a ds_read of a ready-made pair costs no VALU slot.
+    __shared__ float4 s_b0[BATCH];      // x, x, y, y
+    __shared__ float4 s_b1[BATCH];      // conic a, a, conic b, b
+    __shared__ float4 s_b2[BATCH];      // conic c, c, opacity, opacity
+    __shared__ float4 s_b3[BATCH];      // r, r, g, g
+    __shared__ float4 s_b4[BATCH];      // b, b, qmax (cull threshold), -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
     __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (both waves add into it)
@@ -120,6 +125,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
     const v2f pxf = { (float)pxA, (float)pxB };
     const float pyf = (float)py;
+    const v2f pyv = { pyf, pyf };
     const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
     const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
     const size_t N = (size_t)W * H;
@@ -176,9 +182,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = a;
-            s_q1[tid] = make_float4(b.x, c.z, b.y, 0.f);
-            s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
+            s_b0[tid] = make_float4(a.x, a.x, a.y, a.y);
+            s_b1[tid] = make_float4(a.z, a.z, a.w, a.w);
+            s_b2[tid] = make_float4(b.x, b.x, b.y, b.y);
+            s_b3[tid] = make_float4(b.z, b.z, b.w, b.w);
+            s_b4[tid] = make_float4(c.x, c.x, c.z, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
         }
@@ -192,10 +200,12 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             {
                 const int j = sb + l;
                 if (j < cnt && (uint32_t)(pos_hi - j) < wave_last) {
-                    const float4 a = s_q0[j];
-                    const float4 b = s_q1[j];
+                    const float4 a = s_b0[j];
+                    const float4 b = s_b1[j];
+                    const float4 c = s_b2[j];
+                    const float4 e = s_b4[j];
                     const float2 r = s_q3[j];
-                    hit = box_hit(a.x, a.y, a.z, a.w, b.x, r.x, r.y, b.y, bx0, bx1, by0, by1);
+                    hit = box_hit(a.x, a.z, b.x, b.z, c.x, r.x, r.y, e.z, bx0, bx1, by0, by1);
                 }
             }
             uint64_t mask = __ballot(hit);
@@ -204,14 +214,16 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 mask &= mask - 1;
                 const int j = sb + k;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
-                const float4 a = s_q0[j];
-                const float4 b = s_q1[j];
-                const float4 c = s_q2[j];
-                const v2f dx = a.x - pxf;
-                const float dy = a.y - pyf;
-                const v2f power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const float4 p0 = s_b0[j], p1 = s_b1[j], p2 = s_b2[j], p3 = s_b3[j];
+                const float4 p4 = s_b4[j];
+                const v2f gxv = { p0.x, p0.y }, gyv = { p0.z, p0.w }, ca = { p1.x, p1.y }, cb = { p1.z, p1.w };
+                const v2f cc = { p2.x, p2.y }, op = { p2.z, p2.w }, cr = { p3.x, p3.y }, cg = { p3.z, p3.w };
+                const v2f cbl = { p4.x, p4.y };
+                const v2f dx = gxv - pxf;
+                const v2f dy = gyv - pyv;
+                const v2f power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
                 const v2f Graw = { __expf(power.x), __expf(power.y) };
-                const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, b.z * Graw);
+                const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, op * Graw);
                 // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0,
                 // alpha < 1/255  ->  skipped; here: processed as a layer with alpha = 0, G = 0
                 const bool vA = pos < lastA && power.x <= 0.0f && araw.x >= 1.0f / 255.0f;
@@ -227,21 +239,24 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 acr = last_alpha * lcr + oml * acr;
                 acg = last_alpha * lcg + oml * acg;
                 acb = last_alpha * lcb + oml * acb;
-                lcr = v2f{ c.x, c.x }; lcg = v2f{ c.y, c.y }; lcb = v2f{ c.z, c.z };
+                lcr = cr; lcg = cg; lcb = cbl;
                 last_alpha = alpha;
-                v2f dL_dalpha = (c.x - acr) * dLr + (c.y - acg) * dLg + (c.z - acb) * dLb;
+                v2f dL_dalpha = (cr - acr) * dLr + (cg - acg) * dLg + (cbl - acb) * dLb;
                 dL_dalpha = dL_dalpha * T - bgT * rinv;
                 const v2f dop = G * dL_dalpha;                    // G * dL/dalpha
-                const v2f sG = b.z * dop;                         // (o * dL/dalpha) * G
+                const v2f sG = op * dop;                          // (o * dL/dalpha) * G
                 const v2f sdx = sG * dx, sdy = sG * dy;
-                const v2f t_dmx = (-a.z * sdx - a.w * sdy) * ddelx_dx;
-                const v2f t_dmy = (-b.x * sdy - a.w * sdx) * ddely_dy;
+                const v2f t_dmx = (-ca * sdx - cb * sdy) * ddelx_dx;
+                const v2f t_dmy = (-cc * sdy - cb * sdx) * ddely_dy;
                 const v2f t_dca = -0.5f * sdx * dx, t_dcb = -0.5f * sdx * dy, t_dcc = -0.5f * sdy * dy;
                 const v2f t_dr = dchan * dLr, t_dg = dchan * dLg, t_db = dchan * dLb;
                 // the lane's two pixels add up first, then the wave reduction of the nine terms
-                const float ra = reduce4(t_dmx.x + t_dmx.y, t_dmy.x + t_dmy.y, t_dca.x + t_dca.y, t_dcb.x + t_dcb.y);
-                const float rb = reduce4(t_dcc.x + t_dcc.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
-                const float rc = row_sum(t_db.x + t_db.y);        // every row: its partial of db
+                float ra = reduce4(t_dmx.x + t_dmx.y, t_dmy.x + t_dmy.y, t_dca.x + t_dca.y, t_dcb.x + t_dcb.y);
+                float rb = reduce4(t_dcc.x + t_dcc.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
+                float rc = row_sum(t_db.x + t_db.y);              // every row: its partial of db
+                // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
+                // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
+                asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
                 float* dst = s_acc[j];
                 if (row_leader) {
                     atomicAdd(dst + col_a, ra);
