@@ -8,8 +8,13 @@ the binning buffer is sized from the high-water mark of num_rendered seen so far
 (P, H, W) times a headroom factor.  Every async forward leaves its true count and an overflow flag in
 the geom-buffer header; a non-blocking copy of the header is polled on later calls.  If a view ever
 overflowed, the NEXT rasterizer call raises (that earlier image was incomplete) -- callers that cannot
-accept a deferred error keep exact mode.
+accept a deferred error keep exact mode.  The first `warm_calls` forwards of every (P, H, W) still run exact, so
+that the mark is taken over several views of a camera path rather than the first one only; a training loop whose
+counts keep growing (scales change, densification) can pass on_overflow="warn" to keep going with a raised
+capacity instead of an exception.
 """
+import warnings
+
 import torch
 
 _async = False
@@ -20,15 +25,25 @@ _pending = []        # [(event, pinned_header, key)]
 _CHECK_EVERY = 8      # async mode: every k-th forward gets its header copied back and checked
 _calls = 0
 _pinned_pool = []
+_warm_calls = 1
+_seen = {}           # key -> forwards seen
+_on_overflow = "raise"
 
 
-def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 8):
+def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 8, warm_calls: int = 1,
+              on_overflow: str = "raise"):
     """check_every: every k-th async forward has its header (true instance count, overflow flag) copied back
-    without blocking and examined on a later call; 1 checks every view."""
-    global _async, _headroom, _CHECK_EVERY
+    without blocking and examined on a later call; 1 checks every view.
+    warm_calls: the first this-many forwards of a (P, H, W) run in exact mode and feed the high-water mark.
+    on_overflow: "raise" (default) or "warn" when a deferred overflow is discovered."""
+    global _async, _headroom, _CHECK_EVERY, _warm_calls, _on_overflow
+    if on_overflow not in ("raise", "warn"):
+        raise ValueError("on_overflow must be 'raise' or 'warn'")
     _async = bool(enabled)
     _headroom = float(headroom)
     _CHECK_EVERY = max(1, int(check_every))
+    _warm_calls = max(1, int(warm_calls))
+    _on_overflow = on_overflow
     if not enabled:
         drain()
 
@@ -55,6 +70,7 @@ def is_async() -> bool:
 def reset():
     drain()
     _hwm.clear()
+    _seen.clear()
 
 
 def _key(means3D, rs):
@@ -75,7 +91,10 @@ def _poll(block=False):
             _hwm[key] = num_rendered
         if trap:
             raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
-        if overflow:
+        if overflow and _on_overflow == "warn":
+            warnings.warn(f"luciddreamer_amd async mode: a view needed {num_rendered} tile instances, more than its "
+                          "binning capacity; its image/gradient was incomplete (capacity has been raised)")
+        elif overflow:
             raise RuntimeError(
                 f"luciddreamer_amd async mode: an earlier view needed {num_rendered} tile instances, more than its "
                 "binning capacity; that image/gradient was incomplete. Re-run it (capacity has been raised) or use "
@@ -92,9 +111,12 @@ def capacity_for(means3D, rs) -> int:
     if not _async or means3D.shape[0] == 0:
         return 0
     _poll()
-    est = _hwm.get(_key(means3D, rs))
-    if est is None:
-        return 0                      # first sighting of this problem size: measure exactly
+    key = _key(means3D, rs)
+    est = _hwm.get(key)
+    n = _seen.get(key, 0)
+    _seen[key] = n + 1
+    if est is None or (_warm_calls > 1 and n < _warm_calls):
+        return 0                      # first sighting(s) of this problem size: measure exactly
     return int(est * _headroom) + 4096
 
 
