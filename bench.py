@@ -227,7 +227,8 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c3.json")
     if args.workload == "c3" and args.gaussians is None and os.path.exists(pmc_path):
         try:
-            pmc = json.load(open(pmc_path)).get("k_" + dom, {})
+            allpmc = json.load(open(pmc_path))
+            pmc = allpmc.get("k_" + dom) or allpmc.get("k_" + dom + "<false>") or {}
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
             if "SQ_INSTS_VALU" in pmc:
