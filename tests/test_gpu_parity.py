@@ -208,6 +208,49 @@ def test_async_mode_matches_exact(hip_device):
         _C.check(out[4])
 
 
+def test_async_mode_warm_calls_and_overflow_policy(hip_device):
+    """warm_calls exact forwards feed the high-water mark; a deferred overflow raises by default and only warns with
+    on_overflow="warn" (the capacity is raised either way and later views are complete again)."""
+    import warnings
+    from luciddreamer_amd import config
+    cloud = synthetic.make_cloud(120_000, "band", 4)          # ~20 k tile instances per view: well above the +4096 slack
+    cams = cameras.rotate360_path(384, 256, n_views=8)
+    bg = torch.zeros(3)
+    g = synthetic.upstream_grad(256, 384)
+    exact = [hp.run_hip(cloud, c, 3, bg, hip_device, g) for c in cams]
+    config.reset()
+    config.set_async(True, headroom=1.2, check_every=1, warm_calls=len(cams))
+    try:
+        warm = [hp.run_hip(cloud, c, 3, bg, hip_device, g) for c in cams]          # all exact, mark = max over the path
+        key = next(iter(config._hwm))
+        assert config._seen[key] == len(cams)
+        later = [hp.run_hip(cloud, c, 3, bg, hip_device, g) for c in cams]         # async with enough capacity
+        config.drain()
+        for a, b, c in zip(exact, warm, later):
+            assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["color"], c["color"])
+        # shrink the mark artificially: the next view overflows; "warn" keeps going
+        config.set_async(True, headroom=1.0, check_every=1, warm_calls=1, on_overflow="warn")
+        config._hwm[key] = 64
+        hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            config.drain()
+        assert any("binning capacity" in str(x.message) for x in w)
+        assert config._hwm[key] > 64                                               # raised from the true count
+        config.set_async(True, headroom=1.3, check_every=1)
+        again = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
+        config.drain()
+        assert np.array_equal(again["color"], exact[0]["color"])
+        # default policy: raise
+        config._hwm[key] = 64
+        hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
+        with pytest.raises(RuntimeError, match="capacity"):
+            config.drain()
+    finally:
+        config.set_async(False)
+        config.reset()
+
+
 def test_fused_grad_accumulation_equals_autograd(hip_device):
     """In-kernel `grad += view gradient` (leaf .grad preallocated) == autograd's dense accumulate, over 3 views."""
     from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
