@@ -89,7 +89,8 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-// s_acc column of each term: 0 dmx, 1 dmy, 2 dca, 3 dcb, 4 dcc, 5 dop, 6 dr, 7 dg, 8 db (= GradRec float order)
+// s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
+// 8 db; the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
 //
 // 128 threads = 2 wave64 per 16x16 tile; a wave owns a 16x8 half tile, a lane owns TWO pixels (same row, 8
 // columns apart) and all per-pixel arithmetic is packed FP32 on 2-vectors.  The blend recursion is
@@ -243,16 +244,16 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 last_alpha = alpha;
                 v2f dL_dalpha = (cr - acr) * dLr + (cg - acg) * dLg + (cbl - acb) * dLb;
                 dL_dalpha = dL_dalpha * T - bgT * rinv;
+                // Per pixel only the moments of D = G * dL/dalpha are formed: D, D dx, D dy, D dx^2, D dx dy, D dy^2.
+                // The factors that are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of
+                // backward.cu:473-474) are applied once per instance when the batch is flushed.
                 const v2f dop = G * dL_dalpha;                    // G * dL/dalpha
-                const v2f sG = op * dop;                          // (o * dL/dalpha) * G
-                const v2f sdx = sG * dx, sdy = sG * dy;
-                const v2f t_dmx = (-ca * sdx - cb * sdy) * ddelx_dx;
-                const v2f t_dmy = (-cc * sdy - cb * sdx) * ddely_dy;
-                const v2f t_dca = -0.5f * sdx * dx, t_dcb = -0.5f * sdx * dy, t_dcc = -0.5f * sdy * dy;
+                const v2f mx = dop * dx, my = dop * dy;
+                const v2f mxx = mx * dx, mxy = mx * dy, myy = my * dy;
                 const v2f t_dr = dchan * dLr, t_dg = dchan * dLg, t_db = dchan * dLb;
                 // the lane's two pixels add up first, then the wave reduction of the nine terms
-                float ra = reduce4(t_dmx.x + t_dmx.y, t_dmy.x + t_dmy.y, t_dca.x + t_dca.y, t_dcb.x + t_dcb.y);
-                float rb = reduce4(t_dcc.x + t_dcc.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
+                float ra = reduce4(mx.x + mx.y, my.x + my.y, mxx.x + mxx.y, mxy.x + mxy.y);
+                float rb = reduce4(myy.x + myy.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
                 float rc = row_sum(t_db.x + t_db.y);              // every row: its partial of db
                 // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
                 // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
@@ -269,10 +270,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         if (tid < cnt) {
             // every instance owns one 48-byte slot: plain stores, no atomics, and the per-Gaussian sum in
             // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed)
-            const float* a9 = s_acc[tid];
+            const float* a9 = s_acc[tid];              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db
+            const float4 q1 = s_b1[tid], q2 = s_b2[tid];
+            const float ca = q1.x, cb = q1.z, cc = q2.x, o = q2.z;
+            const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
-            slot[0] = make_float4(a9[0], a9[1], a9[2], a9[3]);
-            slot[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+            slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
+            slot[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
             slot[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
         }
     }
