@@ -147,8 +147,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     if (insA) { dLr.x = dL_dpix[pixA]; dLg.x = dL_dpix[N + pixA]; dLb.x = dL_dpix[2 * N + pixA]; }
     if (insB) { dLr.y = dL_dpix[pixB]; dLg.y = dL_dpix[N + pixB]; dLb.y = dL_dpix[2 * N + pixB]; }
     const v2f bgT = (bg[0] * dLr + bg[1] * dLg + bg[2] * dLb) * T_final;      // T_final * bg . dL/dpixel
-    v2f acr = { 0.f, 0.f }, acg = acr, acb = acr;      // accum_rec
-    v2f last_alpha = acr, lcr = acr, lcg = acr, lcb = acr;
+    v2f A = { 0.f, 0.f };                              // accum_rec . dL/dpixel
+    v2f last_alpha = A, lcdl = A;                      // alpha and (colour . dL/dpixel) of the previous layer
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
 
@@ -236,13 +236,14 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const v2f rinv = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };   // one v_rcp per pixel
                 T = T * rinv;
                 const v2f dchan = alpha * T;
-                const v2f oml = 1.0f - last_alpha;
-                acr = last_alpha * lcr + oml * acr;
-                acg = last_alpha * lcg + oml * acg;
-                acb = last_alpha * lcb + oml * acb;
-                lcr = cr; lcg = cg; lcb = cbl;
+                // The colour recursion of backward.cu:517-533 (accum_rec per channel, then sum over channels of
+                // (c - accum_rec) * dL/dpixel) only ever enters through its dot product with this pixel's dL/dpixel, which
+                // is constant along the list: carry A = accum_rec . dL instead of three accumulators.
+                const v2f cdl = cr * dLr + cg * dLg + cbl * dLb;  // colour of this Gaussian . dL/dpixel
+                A = A + last_alpha * (lcdl - A);                  // = last_alpha * lcdl + (1 - last_alpha) * A
+                lcdl = cdl;
                 last_alpha = alpha;
-                v2f dL_dalpha = (cr - acr) * dLr + (cg - acg) * dLg + (cbl - acb) * dLb;
+                v2f dL_dalpha = cdl - A;
                 dL_dalpha = dL_dalpha * T - bgT * rinv;
                 // Per pixel only the moments of D = G * dL/dalpha are formed: D, D dx, D dy, D dx^2, D dx dy, D dy^2.
                 // The factors that are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of
