@@ -178,6 +178,18 @@ __device__ __forceinline__ float cull_qmax(float opacity)
 }
 
 // ---- launchers (one per translation unit) ------------------------------------------------------
+// Exponent of a splat at two pixels of one row (x offsets dx, common y offset dy):
+//   power = -0.5 (a dx^2 + c dy^2) - b dx dy  (forward.cu:332-334)  =  (Ap dx + Bp dy) dx + Cp dy dy
+// with Ap = -0.5 a, Bp = -b, Cp = -0.5 c formed once per Gaussian when it is staged.  ONE definition shared by the
+// blend forward and backward, so both kernels evaluate alpha with the same operations.
+typedef float lr_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ lr_v2f gauss_power(float Ap, float Bp, float Cp, lr_v2f dx, float dy)
+{
+    const float Bd = Bp * dy;
+    const float Cdd = (Cp * dy) * dy;
+    return (Ap * dx + Bd) * dx + Cdd;
+}
+
 struct ViewParams {
     const float* view;      // device, 16 floats, flat index m[4*col+row] (auxiliary.h:58-77)
     const float* proj;      // device, 16 floats

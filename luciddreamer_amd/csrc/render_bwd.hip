@@ -108,8 +108,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     // scalar operand that sits in an odd register (or must be broadcast) costs a v_mov per use in this VALU-issue-bound
     // loop; a ds_read of a ready-made pair costs no VALU slot.
     __shared__ float4 s_b0[BATCH];      // x, x, y, y
-    __shared__ float4 s_b1[BATCH];      // conic a, a, conic b, b
-    __shared__ float4 s_b2[BATCH];      // conic c, c, opacity, opacity
+    __shared__ float4 s_b1[BATCH];      // Ap = -0.5 conic a, Ap, Bp = -conic b, Bp     (common.h gauss_power)
+    __shared__ float4 s_b2[BATCH];      // Cp = -0.5 conic c, Cp, opacity, opacity
     __shared__ float4 s_b3[BATCH];      // r, r, g, g
     __shared__ float4 s_b4[BATCH];      // b, b, qmax (cull threshold), -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
@@ -126,7 +126,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
     const v2f pxf = { (float)pxA, (float)pxB };
     const float pyf = (float)py;
-    const v2f pyv = { pyf, pyf };
     const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
     const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
     const size_t N = (size_t)W * H;
@@ -184,8 +183,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_b0[tid] = make_float4(a.x, a.x, a.y, a.y);
-            s_b1[tid] = make_float4(a.z, a.z, a.w, a.w);
-            s_b2[tid] = make_float4(b.x, b.x, b.y, b.y);
+            s_b1[tid] = make_float4(-0.5f * a.z, -0.5f * a.z, -a.w, -a.w);
+            s_b2[tid] = make_float4(-0.5f * b.x, -0.5f * b.x, b.y, b.y);
             s_b3[tid] = make_float4(b.z, b.z, b.w, b.w);
             s_b4[tid] = make_float4(c.x, c.x, c.z, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
@@ -206,7 +205,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                     const float4 c = s_b2[j];
                     const float4 e = s_b4[j];
                     const float2 r = s_q3[j];
-                    hit = box_hit(a.x, a.z, b.x, b.z, c.x, r.x, r.y, e.z, bx0, bx1, by0, by1);
+                    hit = box_hit(a.x, a.z, -2.0f * b.x, -b.z, -2.0f * c.x, r.x, r.y, e.z, bx0, bx1, by0, by1);   // exact inverses
                 }
             }
             uint64_t mask = __ballot(hit);
@@ -217,12 +216,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 const float4 p0 = s_b0[j], p1 = s_b1[j], p2 = s_b2[j], p3 = s_b3[j];
                 const float4 p4 = s_b4[j];
-                const v2f gxv = { p0.x, p0.y }, gyv = { p0.z, p0.w }, ca = { p1.x, p1.y }, cb = { p1.z, p1.w };
-                const v2f cc = { p2.x, p2.y }, op = { p2.z, p2.w }, cr = { p3.x, p3.y }, cg = { p3.z, p3.w };
+                const v2f gxv = { p0.x, p0.y };
+                const v2f op = { p2.z, p2.w }, cr = { p3.x, p3.y }, cg = { p3.z, p3.w };
                 const v2f cbl = { p4.x, p4.y };
                 const v2f dx = gxv - pxf;
-                const v2f dy = gyv - pyv;
-                const v2f power = -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+                const float dys = p0.z - pyf;                     // both pixels of a lane share the row
+                const v2f dy = { dys, dys };
+                const v2f power = gauss_power(p1.x, p1.z, p2.x, dx, dys);
                 const v2f Graw = { __expf(power.x), __expf(power.y) };
                 const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, op * Graw);
                 // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0,
@@ -273,7 +273,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed)
             const float* a9 = s_acc[tid];              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db
             const float4 q1 = s_b1[tid], q2 = s_b2[tid];
-            const float ca = q1.x, cb = q1.z, cc = q2.x, o = q2.z;
+            const float ca = -2.0f * q1.x, cb = -q1.z, cc = -2.0f * q2.x, o = q2.z;
             const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);

@@ -44,8 +44,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ out_color, float* __restrict__ out_depth)
 {
-    __shared__ float4 s_q0[BATCH];      // x, y, conic a, conic b
-    __shared__ float4 s_q1[BATCH];      // conic c, qmax (cull threshold), opacity, depth
+    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, qmax (cull threshold), opacity, depth
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a (edge minimiser slopes for box_hit)
     __shared__ int s_wdone[2];
@@ -80,8 +80,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = a;
-            s_q1[tid] = make_float4(b.x, c.z, b.y, c.y);
+            s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
+            s_q1[tid] = make_float4(-0.5f * b.x, c.z, b.y, c.y);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
         }
@@ -97,7 +97,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                     const float4 a = s_q0[j];
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    hit = box_hit(a.x, a.y, a.z, a.w, b.x, r.x, r.y, b.y, bx0, bx1, by0, by1);
+                    hit = box_hit(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * b.x, r.x, r.y, b.y, bx0, bx1, by0, by1);   // exact inverses
                 }
             }
             uint64_t mask = __ballot(hit);
@@ -111,7 +111,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float4 c = s_q2[j];
                 const v2f dx = a.x - pxf;
                 const float dy = a.y - pyf;
-                const v2f power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const v2f power = gauss_power(a.z, a.w, b.x, dx, dy);
                 const v2f G = { __expf(power.x), __expf(power.y) };
                 const v2f alpha = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, b.z * G);
                 const v2f test_T = T * (1.0f - alpha);
