@@ -221,7 +221,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const v2f cbl = { p4.x, p4.y };
                 const v2f dx = gxv - pxf;
                 const float dys = p0.z - pyf;                     // both pixels of a lane share the row
-                const v2f dy = { dys, dys };
                 const v2f power = gauss_power(p1.x, p1.z, p2.x, dx, dys);
                 const v2f Graw = { __expf(power.x), __expf(power.y) };
                 const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, op * Graw);
@@ -249,12 +248,16 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 // The factors that are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of
                 // backward.cu:473-474) are applied once per instance when the batch is flushed.
                 const v2f dop = G * dL_dalpha;                    // G * dL/dalpha
-                const v2f mx = dop * dx, my = dop * dy;
-                const v2f mxx = mx * dx, mxy = mx * dy, myy = my * dy;
+                // both pixels of a lane share dy, so the dy factors are applied to the lane's pair sums (scalar ops)
+                const v2f mx = dop * dx;
+                const v2f mxx = mx * dx;
                 const v2f t_dr = dchan * dLr, t_dg = dchan * dLg, t_db = dchan * dLb;
+                const float sD = dop.x + dop.y, sMx = mx.x + mx.y, sMxx = mxx.x + mxx.y;
+                const float sMy = dys * sD, sMxy = dys * sMx;
+                const float sMyy = dys * sMy;
                 // the lane's two pixels add up first, then the wave reduction of the nine terms
-                float ra = reduce4(mx.x + mx.y, my.x + my.y, mxx.x + mxx.y, mxy.x + mxy.y);
-                float rb = reduce4(myy.x + myy.y, dop.x + dop.y, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
+                float ra = reduce4(sMx, sMy, sMxx, sMxy);
+                float rb = reduce4(sMyy, sD, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
                 float rc = row_sum(t_db.x + t_db.y);              // every row: its partial of db
                 // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
                 // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
