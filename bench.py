@@ -232,9 +232,10 @@ def main():
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
             if "SQ_INSTS_VALU" in pmc:
-                # the blend kernels are VALU-issue bound: wave-instructions per launch from the
-                # PMC pass over this launch's measured duration, against 256 CUs x 4 SIMDs x one VALU issue per 4
-                # cycles at 2.4 GHz (a v_fma_f32 micro-benchmark reaches 537 G/s)
+                # the blend kernels are VALU bound: wave-instructions per launch from the PMC
+                # pass over this launch's measured duration.  Reference rates (tools/valu_microbench.hip on MI355X):
+                # 912 G wave-instr/s for v_fma_f32, 453 G/s for v_pk_fma_f32; "peak" below is 256 CUs x 4 SIMDs x
+                # one issue per 4 cycles at 2.4 GHz, the rate of an all-packed instruction stream
                 ginst = pmc["SQ_INSTS_VALU"] / dom_avg_s / 1e9
                 valu = {"wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_ginst_s": round(ginst, 1),
                         "peak_ginst_s": 614.4, "frac": round(ginst / 614.4, 4)}

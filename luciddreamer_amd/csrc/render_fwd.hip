@@ -6,10 +6,11 @@
 // the execution shape is chosen to minimise wave-instructions per pixel x Gaussian pair:
 //   * one 128-thread workgroup per 16x16 tile = 2 wave64; a wave owns a 16x8 half tile and every LANE owns
 //     TWO pixels (same row, 8 columns apart).  All per-pixel arithmetic is written on 2-vectors and compiles
-//     to packed FP32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): on MI355X a packed instruction issues in
-//     the same ~4 cycles as a scalar one (measured 530 vs 537 G wave-instr/s), i.e. twice the pixels per
-//     issue slot.  The blend is branch-free: a pixel that skips a Gaussian blends it with weight 0, which
-//     is arithmetically identical to the reference's `continue`.
+//     to packed FP32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  A packed instruction costs twice the issue
+//     cycles of a scalar one on MI355X (tools/valu_microbench.hip: 453 vs 912 G wave-instr/s), so the flops are
+//     the same; what two pixels per lane buys is half the per-candidate overhead per pixel (candidate walk, LDS
+//     reads and, in the backward, the cross-lane reduction).  The blend is branch-free: a pixel that skips a
+//     Gaussian blends it with weight 0, which is arithmetically identical to the reference's `continue`.
 //   * every field the inner loop touches is staged in LDS (the reference re-reads colour and depth
 //     from global memory per pixel per Gaussian, forward.cu:359, 364);
 //   * two-level loop per wave.  CULL: 64 staged Gaussians at a time, one per LANE, are tested against the
