@@ -99,7 +99,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // branch-free: a pixel for which the Gaussian is skipped processes it as a layer with alpha = 0 and G = 0,
 // which leaves T, accum_rec and every gradient term exactly unchanged (T * rcp(1-0) = T; the colour
 // recursion folds the previous contributor in once, then passes it through with weight 1).
-__global__ void __launch_bounds__(THREADS)
+// 7 waves per SIMD (<= 72 VGPRs): measured 2 % faster than the 78 registers / 6 waves the compiler picks, 8 is slower
+__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
