@@ -148,9 +148,12 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     v2f dLr = { 0.f, 0.f }, dLg = dLr, dLb = dLr;
     if (insA) { dLr.x = dL_dpix[pixA]; dLg.x = dL_dpix[N + pixA]; dLb.x = dL_dpix[2 * N + pixA]; }
     if (insB) { dLr.y = dL_dpix[pixB]; dLg.y = dL_dpix[N + pixB]; dLb.y = dL_dpix[2 * N + pixB]; }
-    const v2f bgT = (bg[0] * dLr + bg[1] * dLg + bg[2] * dLb) * T_final;      // T_final * bg . dL/dpixel
-    v2f A = { 0.f, 0.f };                              // accum_rec . dL/dpixel
-    v2f last_alpha = A, lcdl = A;                      // alpha and (colour . dL/dpixel) of the previous layer
+    const v2f bgdl = bg[0] * dLr + bg[1] * dLg + bg[2] * dLb;                 // background . dL/dpixel
+    // A = (colour seen BEHIND the current layer, background included) . dL/dpixel.  The reference keeps the background in
+    // a separate term, -T_final/(1-alpha) * bg.dL (backward.cu:556-560); T_final/(1-alpha_i) = T_i * prod_{j>i}(1-alpha_j),
+    // i.e. the background is simply the last layer of the same recursion: start A at bg.dL instead of 0.
+    v2f A = bgdl;
+    v2f last_alpha = { 0.f, 0.f }, lcdl = last_alpha;  // alpha and (colour . dL/dpixel) of the previous layer
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
 
@@ -246,7 +249,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 lcdl = cdl;
                 last_alpha = alpha;
                 v2f dL_dalpha = cdl - A;
-                dL_dalpha = dL_dalpha * T - bgT * rinv;
+                dL_dalpha = dL_dalpha * T;
                 // Per pixel only the moments of D = G * dL/dalpha are formed: D, D dx, D dy, D dx^2, D dx dy, D dy^2.
                 // The factors that are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of
                 // backward.cu:473-474) are applied once per instance when the batch is flushed.
