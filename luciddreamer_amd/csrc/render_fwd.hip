@@ -124,7 +124,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const bool stopB = passB && test_T.y < 0.0001f;
                 doneA = doneA || stopA;
                 doneB = doneB || stopB;
-                const bool useA = passA && !stopA, useB = passB && !stopB;
+                const bool useA = passA != stopA, useB = passB != stopB;     // stop implies pass: xor of the lane masks
                 const v2f wgt = { useA ? alpha.x * T.x : 0.f, useB ? alpha.y * T.y : 0.f };
                 Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
                 Dacc += b.w * wgt;
