@@ -5,6 +5,7 @@ piece of this repository on the MI355X:
     render_raw        rasterizer fed with the stored parameters (activations inside the kernels)      8a-8d, 8f-2
     l1_dssim_loss     fused (1-l)*L1 + l*(1-SSIM) and its gradient                                     8f-3
     densify           densify_and_prune / prune through one row-selection kernel, Adam state intact     8f-4
+    FusedAdam         torch.optim.Adam's arithmetic in one launch per step                              (8e: the step after the all-reduce)
     distCUDA2         initial scales from the 3-nearest-neighbour distance                              8f-1
 
 Targets are renders of a hidden "ground truth" cloud from a look-around camera path; the trained cloud starts from
@@ -25,6 +26,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from luciddreamer_amd import cameras, config, densify, synthetic           # noqa: E402
 from luciddreamer_amd.gaussian_renderer import GaussianCloud, render_raw   # noqa: E402
 from luciddreamer_amd.loss import l1_dssim_loss                            # noqa: E402
+from luciddreamer_amd.optim import FusedAdam                               # noqa: E402
 from simple_knn._C import distCUDA2                                        # noqa: E402
 
 GROUP_ATTR = densify.GROUP_ATTR
@@ -33,7 +35,7 @@ GROUP_ATTR = densify.GROUP_ATTR
 class TrainableCloud(GaussianCloud):
     """GaussianCloud + what GaussianModel.training_setup adds (scene/gaussian_model.py:148-169)."""
 
-    def training_setup(self, lrs, percent_dense=0.01):
+    def training_setup(self, lrs, percent_dense=0.01, torch_adam=False):
         P = self._xyz.shape[0]
         dev = self._xyz.device
         for a in GROUP_ATTR.values():
@@ -43,7 +45,7 @@ class TrainableCloud(GaussianCloud):
         self.denom = torch.zeros((P, 1), device=dev)
         self.max_radii2D = torch.zeros((P,), device=dev)
         groups = [{"params": [getattr(self, a)], "lr": lrs[n], "name": n} for n, a in GROUP_ATTR.items()]
-        self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        self.optimizer = (torch.optim.Adam if torch_adam else FusedAdam)(groups, lr=0.0, eps=1e-15)
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter):     # gaussian_model.py:405-407
         # same sums as the reference's boolean-mask indexing, written without the host synchronisation that indexing
@@ -72,7 +74,8 @@ def build(args, dev):
     shs = torch.zeros(idx.numel(), 16, 3, device=dev)
     shs[:, 0] = gt_cloud["shs"][idx, 0]
     model = TrainableCloud(xyz, scales, rots, torch.full((idx.numel(), 1), 0.1, device=dev), shs)
-    model.training_setup({"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3})
+    model.training_setup({"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3},
+                         torch_adam=args.torch_adam)
     return model, cams, targets
 
 
@@ -113,7 +116,7 @@ def train(args, log=print):
 
 def default_args(**kw):
     d = dict(gaussians=200_000, iters=300, resolution="512x512", views=12, lambda_dssim=0.2, log=50, densify_from=100,
-             densify_every=100, densify_until=10_000, exact=False)
+             densify_every=100, densify_until=10_000, exact=False, torch_adam=False)
     d.update(kw)
     return SimpleNamespace(**d)
 

@@ -282,6 +282,19 @@ int lr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, c
                      const float* opacity, const float* scaling, const float* rotation, float* out_rows, void* stream);
 
 /*
+ * One-launch Adam step over the parameter tensors of a GaussianModel (the optimiser step after the gradient
+ * all-reduce of the data-parallel step; the reference uses torch.optim.Adam(l, lr=0.0, eps=1e-15) with one param group
+ * -- one learning rate -- per tensor, R/scene/gaussian_model.py:152-165).  Formula and operation order of torch's
+ * single-tensor Adam without weight decay / amsgrad / maximize.  params, grads, exp_avg, exp_avg_sq, numel, lr are
+ * HOST arrays of n_tensors (<= 16) entries (device pointers / element counts / learning rates); step is the 1-based
+ * step count of these tensors.  Hyper-parameters are doubles (as in Python) and rounded to float once, after
+ * 1 - beta and lr / (1 - beta1^t) have been formed.  Updates params, exp_avg, exp_avg_sq in place.
+ */
+int lr_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,
+                 double eps, int step, void* stream);
+
+/*
  * Fused photometric loss of the training loop:
  *     loss = (1 - lambda) * mean|image - gt| + lambda * (1 - mean(SSIM_map(image, gt)))
  * replacing l1_loss + ssim of R/utils/loss.py:18-69 as composed in R/luciddreamer.py:301-304 (11x11 window = outer

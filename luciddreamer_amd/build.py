@@ -30,6 +30,7 @@ SOURCES = {
     "knn.hip": [],
     "loss.hip": [],
     "rows.hip": [],
+    "adam.hip": [],
     "api.hip": [],
 }
 

@@ -1,0 +1,87 @@
+// adam.hip -- one-launch Adam step over all parameter tensors of a GaussianModel (the optimiser step that follows the
+// gradient all-reduce of the data-parallel step; torch.optim.Adam(l, lr=0.0, eps=1e-15) in
+// R/scene/gaussian_model.py:165 with one param group, hence one learning rate, per tensor).
+//
+// torch's default (foreach) Adam runs ~10 elementwise kernels per step over every tensor; this is one pass:
+// 16 B read + 12 B written per element... per element: param, grad, exp_avg, exp_avg_sq read (16 B), param, exp_avg,
+// exp_avg_sq written (12 B).  Same formula and operation order as torch's single-tensor implementation
+// (torch/optim/adam.py _single_tensor_adam, no weight decay, no amsgrad, maximize=False):
+//   exp_avg    <- exp_avg + (1 - beta1) * (grad - exp_avg)                      (lerp_)
+//   exp_avg_sq <- beta2 * exp_avg_sq + (1 - beta2) * grad * grad              (mul_, addcmul_)
+//   denom      <- sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps
+//   param      <- param - (lr / (1 - beta1^t)) * exp_avg / denom                (addcdiv_)
+// HBM-bound, 28 B per element.
+#include "common.h"
+#include <cmath>
+
+namespace lr {
+
+namespace {
+
+constexpr int ADAM_MAX_TENSORS = 16;
+struct AdamTensors {
+    float* p[ADAM_MAX_TENSORS];
+    const float* g[ADAM_MAX_TENSORS];
+    float* m[ADAM_MAX_TENSORS];
+    float* v[ADAM_MAX_TENSORS];
+    unsigned long long n[ADAM_MAX_TENSORS];
+    float step_size[ADAM_MAX_TENSORS];          // lr / (1 - beta1^t), per tensor
+    int count;
+};
+
+__global__ void __launch_bounds__(256)
+k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps)
+{
+    const int t = blockIdx.y;
+    if (t >= T.count) return;
+    float* __restrict__ p = T.p[t];
+    const float* __restrict__ g = T.g[t];
+    float* __restrict__ m = T.m[t];
+    float* __restrict__ v = T.v[t];
+    const unsigned long long n = T.n[t];
+    const float step_size = T.step_size[t];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        // the same roundings as torch's kernels (which hipcc compiles with FMA contraction): lerp = fma(w, b - a, a),
+        // addcmul = fma(value * t1, t2, self), addcdiv = fma(value, t1 / t2, self); mul_, sqrt, div, add are separate
+        mi = __builtin_fmaf(w1, gi - mi, mi);
+        vi = vi * beta2;
+        vi = __builtin_fmaf(w2 * gi, gi, vi);
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] = __builtin_fmaf(-step_size, mi / denom, p[i]);
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+
+}  // namespace
+
+int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,
+                double eps, int step, hipStream_t s)
+{
+    if (n_tensors > ADAM_MAX_TENSORS) return -1;
+    AdamTensors T;
+    T.count = n_tensors;
+    // scalars are formed in double, as Python does for torch.optim.Adam, and rounded to float once
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    unsigned long long max_n = 0;
+    for (int t = 0; t < ADAM_MAX_TENSORS; t++) {
+        const bool on = t < n_tensors;
+        T.p[t] = on ? params[t] : nullptr; T.g[t] = on ? grads[t] : nullptr;
+        T.m[t] = on ? exp_avg[t] : nullptr; T.v[t] = on ? exp_avg_sq[t] : nullptr;
+        T.n[t] = on ? numel[t] : 0;
+        T.step_size[t] = on ? (float)(lr[t] / bc1) : 0.f;
+        if (on && numel[t] > max_n) max_n = numel[t];
+    }
+    if (max_n == 0) return 0;
+    unsigned long long blocks = (max_n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks, n_tensors), dim3(256), 0, s, T, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)std::sqrt(bc2), (float)eps);
+    return 0;
+}
+
+}  // namespace lr

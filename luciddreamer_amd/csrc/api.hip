@@ -587,6 +587,23 @@ int lr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, c
     return 0;
 }
 
+int lr_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                 float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,
+                 double eps, int step, void* stream_)
+{
+    if (n_tensors < 0 || step < 1) return fail(LR_ERR_INVALID_ARG, "n_tensors >= 0 and step >= 1 required");
+    if (n_tensors == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return fail(LR_ERR_INVALID_ARG, "NULL array in lr_adam_step");
+    for (int t = 0; t < n_tensors; t++)
+        if (numel[t] != 0 && (!params[t] || !grads[t] || !exp_avg[t] || !exp_avg_sq[t]))
+            return fail(LR_ERR_INVALID_ARG, "NULL tensor in lr_adam_step");
+    if (lr::launch_adam(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step,
+                        reinterpret_cast<hipStream_t>(stream_)) < 0)
+        return fail(LR_ERR_INVALID_ARG, "at most 16 tensors per lr_adam_step call");
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 size_t lr_loss_workspace_bytes(int channels, int height, int width)
 {
     if (channels <= 0 || height <= 0 || width <= 0) return 0;

@@ -1,0 +1,77 @@
+"""FusedAdam (lr_adam_step) against torch.optim.Adam on the parameter set of a GaussianModel: same updates over many
+steps (float32, a few ulps), same state layout, works with the device-side densification."""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+SHAPES = {"xyz": (3,), "f_dc": (1, 3), "f_rest": (15, 3), "opacity": (1,), "scaling": (3,), "rotation": (4,)}
+LRS = {"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 1.25e-4, "opacity": 0.05, "scaling": 5e-3, "rotation": 1e-3}
+
+
+def _params(P, dev, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: nn.Parameter(torch.randn((P,) + s, generator=g).to(dev)) for k, s in SHAPES.items()}
+
+
+def test_matches_torch_adam(hip_device):
+    from luciddreamer_amd.optim import FusedAdam
+    P = 50_000
+    a, b = _params(P, hip_device, 0), _params(P, hip_device, 0)
+    groups = lambda d: [{"params": [d[k]], "lr": LRS[k], "name": k} for k in SHAPES]
+    ref = torch.optim.Adam(groups(a), lr=0.0, eps=1e-15)
+    fus = FusedAdam(groups(b), lr=0.0, eps=1e-15)
+    g = torch.Generator().manual_seed(1)
+    for it in range(25):
+        for k in SHAPES:
+            grad = (torch.randn((P,) + SHAPES[k], generator=g) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=g)))).to(hip_device)
+            if it % 5 == 0:
+                grad[: P // 2] = 0                                  # rows that were not visible
+            a[k].grad = grad.clone()
+            b[k].grad = grad.clone()
+        if it == 10:
+            for grp in list(ref.param_groups) + list(fus.param_groups):     # update_learning_rate
+                if grp["name"] == "xyz":
+                    grp["lr"] = 1.0e-4
+        ref.step()
+        fus.step()
+    for k in SHAPES:
+        close = lambda x, y: (x - y).abs().max().item() <= 2e-6 * y.abs().max().item()
+        assert close(b[k], a[k]), k
+        sa, sb = ref.state[a[k]], fus.state[b[k]]
+        assert int(sa["step"]) == int(sb["step"]) == 25
+        assert close(sb["exp_avg"], sa["exp_avg"]) and close(sb["exp_avg_sq"], sa["exp_avg_sq"]), k
+
+
+def test_params_without_grad_are_skipped_and_cpu_is_rejected(hip_device):
+    from luciddreamer_amd.optim import FusedAdam
+    p = _params(100, hip_device, 3)
+    opt = FusedAdam([{"params": [p[k]], "lr": LRS[k], "name": k} for k in SHAPES], lr=0.0, eps=1e-15)
+    before = p["rotation"].detach().clone()
+    p["xyz"].grad = torch.ones_like(p["xyz"])
+    opt.step()
+    assert torch.equal(p["rotation"], before) and len(opt.state[p["rotation"]]) == 0
+    q = nn.Parameter(torch.zeros(4, 3))
+    q.grad = torch.ones(4, 3)
+    with pytest.raises(RuntimeError):
+        FusedAdam([q], lr=1e-3).step()
+
+
+def test_works_with_device_densification(hip_device):
+    from luciddreamer_amd import densify as D
+    from luciddreamer_amd.optim import FusedAdam
+    from tests.test_gpu_densify import Model, ATTR
+    m = Model(5000, hip_device, seed=1, with_adam_state=False)
+    m.optimizer = FusedAdam([{"params": [getattr(m, a)], "lr": 1e-3, "name": n} for n, a in ATTR.items()], lr=0.0, eps=1e-15)
+    for a in ATTR.values():
+        getattr(m, a).grad = torch.ones_like(getattr(m, a))
+    m.optimizer.step()
+    mask = torch.rand(5000, generator=torch.Generator().manual_seed(2)) < 0.4
+    keep = ~mask
+    want = m.optimizer.state[m._xyz]["exp_avg"][keep.to(hip_device)].clone()
+    D.prune_points(m, mask.to(hip_device))
+    assert torch.equal(m.optimizer.state[m._xyz]["exp_avg"], want)
+    for a in ATTR.values():
+        getattr(m, a).grad = torch.ones_like(getattr(m, a))
+    m.optimizer.step()                                        # moments follow the re-pointed parameters
+    assert int(m.optimizer.state[m._xyz]["step"]) == 2
