@@ -98,8 +98,7 @@ def train(args, log=print):
         with torch.no_grad():
             vis, radii = pkg["visibility_filter"], pkg["radii"]
             if it < args.densify_until:                                                   # :308-318
-                torch.where(vis, torch.max(model.max_radii2D, radii.float()), model.max_radii2D, out=model.max_radii2D)
-                model.add_densification_stats(pkg["viewspace_points"], vis)
+                densify.add_densification_stats(model, pkg["viewspace_points"], radii)   # :310-311 + stats, one kernel
                 if it >= args.densify_from and it % args.densify_every == 0:
                     densify.densify_and_prune(model, 0.0002, 0.005, 5.0, 20)
             model.optimizer.step()                                                        # :322-324

@@ -274,6 +274,11 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
  *   lr_pack_ply_rows: builds the 17 + 3*(M-1) float vertex records written by GaussianModel.save_ply (:193-208:
  *     x y z nx ny nz, f_dc_*, f_rest_* channel-major, opacity, scale_*, rot_*) in out_rows [P, 17+3(M-1)] (device).
  */
+/* Densification statistics of one rendered view in one pass (R/luciddreamer.py:310-311 and R/scene/gaussian_model.py:405-407):
+ * for every Gaussian with radii > 0: max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL_dmean2D[:, :2]|;
+ * denom += 1.  radii [P] int32, dL_dmean2D [P,3] (the gradient of `means2D`), statistics [P,1], [P,1], [P] float32. */
+int lr_densify_stats(int P, const int* radii, const float* dL_dmean2D, float* xyz_gradient_accum, float* denom,
+                     float* max_radii2D, void* stream);
 size_t lr_select_workspace_bytes(int P);
 int lr_select_rows(int P, const unsigned char* mask, int n_tensors, const void* const* src, void* const* dst,
                    const unsigned* row_bytes, long long dst_row_offset, int* out_count, void* workspace,

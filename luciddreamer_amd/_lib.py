@@ -28,7 +28,7 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward",
-           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step")
+           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats")
 
 
 def lib():
@@ -112,6 +112,8 @@ def lib():
         L.lr_select_rows.argtypes = [ci, vp, ci, vp, vp, vp, ll, vp, vp, ctypes.c_size_t, vp]
         L.lr_pack_ply_rows.restype = ci
         L.lr_pack_ply_rows.argtypes = [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp]
+        L.lr_densify_stats.restype = ci
+        L.lr_densify_stats.argtypes = [ci, vp, vp, vp, vp, vp, vp]
         L.lr_adam_step.restype = ci
         cd = ctypes.c_double
         L.lr_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, vp, cd, cd, cd, ci, vp]

@@ -574,6 +574,18 @@ int lr_select_rows(int P, const unsigned char* mask, int n_tensors, const void* 
     return 0;
 }
 
+int lr_densify_stats(int P, const int* radii, const float* dL_dmean2D, float* xyz_gradient_accum, float* denom,
+                     float* max_radii2D, void* stream_)
+{
+    if (P < 0) return fail(LR_ERR_INVALID_ARG, "P must be >= 0");
+    if (P == 0) return 0;
+    if (!radii || !dL_dmean2D || !xyz_gradient_accum || !denom || !max_radii2D)
+        return fail(LR_ERR_INVALID_ARG, "radii, dL_dmean2D and the three statistics are required");
+    lr::launch_densify_stats(P, radii, dL_dmean2D, xyz_gradient_accum, denom, max_radii2D, reinterpret_cast<hipStream_t>(stream_));
+    LR_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 int lr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, const float* features_rest,
                      const float* opacity, const float* scaling, const float* rotation, float* out_rows, void* stream_)
 {

@@ -264,6 +264,8 @@ int launch_select_rows(int P, const uint8_t* mask, int n_tensors, const void* co
                        const unsigned* row_bytes, long long dst_row_offset, int* out_count, char* ws, hipStream_t s);
 void launch_pack_ply(int P, int n_rest, const float* xyz, const float* f_dc, const float* f_rest, const float* opacity,
                      const float* scaling, const float* rotation, float* out, hipStream_t s);
+void launch_densify_stats(int P, const int* radii, const float* dL_dmean2D, float* accum, float* denom, float* max_radii,
+                          hipStream_t s);
 // one-launch Adam step over several tensors (adam.hip)
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                 float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,

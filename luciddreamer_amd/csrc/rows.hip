@@ -145,7 +145,32 @@ k_pack_ply(int P, int n_rest, const float* __restrict__ xyz, const float* __rest
     out[q] = v;
 }
 
+// Densification statistics of one training view in one pass (R/luciddreamer.py:310-311 and
+// GaussianModel.add_densification_stats, R/scene/gaussian_model.py:405-407): for every visible Gaussian
+//   max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |dL/dmean2D.xy|; denom += 1.
+__global__ void __launch_bounds__(RS_THREADS)
+k_densify_stats(int P, const int* __restrict__ radii, const float* __restrict__ dL_dmean2D,
+                float* __restrict__ accum, float* __restrict__ denom, float* __restrict__ max_radii)
+{
+    const int i = blockIdx.x * RS_THREADS + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;
+    const float gx = dL_dmean2D[3 * (size_t)i], gy = dL_dmean2D[3 * (size_t)i + 1];
+    max_radii[i] = fmaxf(max_radii[i], (float)r);
+    accum[i] += sqrtf(gx * gx + gy * gy);
+    denom[i] += 1.0f;
+}
+
 }  // namespace
+
+void launch_densify_stats(int P, const int* radii, const float* dL_dmean2D, float* accum, float* denom, float* max_radii,
+                          hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_densify_stats, dim3((P + RS_THREADS - 1) / RS_THREADS), dim3(RS_THREADS), 0, s, P, radii, dL_dmean2D,
+                       accum, denom, max_radii);
+}
 
 size_t select_workspace_bytes(int P)
 {

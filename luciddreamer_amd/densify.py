@@ -212,6 +212,25 @@ def _bind(model, st):
 # ------------------------------------------------------------------------------------------------------------
 # the reference's methods
 # ------------------------------------------------------------------------------------------------------------
+def add_densification_stats(model, viewspace_point_tensor, radii):
+    """The per-iteration bookkeeping of the training loop in one kernel (R/luciddreamer.py:310-311 +
+    GaussianModel.add_densification_stats, gaussian_model.py:405-407): for Gaussians with radii > 0,
+    max_radii2D = max(max_radii2D, radii); xyz_gradient_accum += |viewspace grad[:, :2]|; denom += 1."""
+    g = viewspace_point_tensor.grad
+    P = int(radii.shape[0])
+    ok = lambda t, n: t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == n
+    if g is None or not (ok(g, 3 * P) and ok(model.xyz_gradient_accum, P) and ok(model.denom, P) and ok(model.max_radii2D, P)) \
+            or radii.dtype != torch.int32 or not radii.is_contiguous():
+        raise RuntimeError("add_densification_stats needs contiguous float32 statistics / gradient and int32 radii on a HIP device")
+    L = _lib.lib()
+    dev = radii.device
+    with torch.cuda.device(dev):
+        rc = L.lr_densify_stats(P, radii.data_ptr(), g.data_ptr(), model.xyz_gradient_accum.data_ptr(), model.denom.data_ptr(),
+                                model.max_radii2D.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    if rc < 0:
+        _lib.raise_for(rc, "lr_densify_stats")
+
+
 def prune_points(model, mask):
     """Remove the Gaussians with mask True (gaussian_model.py:290-304)."""
     st = _store(model)

@@ -210,3 +210,21 @@ def test_select_rows_rejects_bad_arguments(hip_device):
     b = torch.zeros(10, 3, device=hip_device)
     assert L.lr_select_rows(10, mask.data_ptr(), 1, arr(a.data_ptr()), arr(b.data_ptr()), rb_bad, 0, cnt.data_ptr(),
                             ws.data_ptr(), ws.numel(), s) == _lib.LR_ERR_INVALID_ARG
+
+
+def test_add_densification_stats(hip_device):
+    from luciddreamer_amd import densify as D
+    P = 30000
+    m = Model(P, hip_device, seed=5)
+    g = torch.Generator().manual_seed(6)
+    radii = torch.randint(-1, 40, (P,), generator=g, dtype=torch.int32).clamp_min(0).to(hip_device)
+    vs = torch.zeros(P, 3, device=hip_device, requires_grad=True)
+    vs.grad = torch.randn(P, 3, generator=g).to(hip_device)
+    acc0, den0, mr0 = m.xyz_gradient_accum.clone(), m.denom.clone(), m.max_radii2D.clone()
+    D.add_densification_stats(m, vs, radii)
+    vis = radii > 0
+    mr0[vis] = torch.max(mr0[vis], radii[vis].float())                                   # luciddreamer.py:310-311
+    acc0[vis] += torch.norm(vs.grad[vis, :2], dim=-1, keepdim=True)                     # gaussian_model.py:406
+    den0[vis] += 1                                                                     # :407
+    assert torch.equal(m.max_radii2D, mr0) and torch.equal(m.denom, den0)
+    assert torch.allclose(m.xyz_gradient_accum, acc0, rtol=1e-6, atol=0)
