@@ -24,7 +24,8 @@ SOURCES = {
     # bit-exact projection / conic / radius vs the CPU oracle: no FMA contraction in this TU
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render_fwd.hip": [],
+    # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
+    "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": [],
     "gauss_bwd.hip": [],
     "knn.hip": [],

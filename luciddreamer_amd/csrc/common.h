@@ -189,6 +189,11 @@ __device__ __forceinline__ lr_v2f gauss_power(float Ap, float Bp, float Cp, lr_v
     const float Cdd = (Cp * dy) * dy;
     return (Ap * dx + Bd) * dx + Cdd;
 }
+// the same expression for ONE pixel
+__device__ __forceinline__ float gauss_power1(float Ap, float Bd, float Cdd, float dx)
+{
+    return (Ap * dx + Bd) * dx + Cdd;
+}
 
 struct ViewParams {
     const float* view;      // device, 16 floats, flat index m[4*col+row] (auxiliary.h:58-77)

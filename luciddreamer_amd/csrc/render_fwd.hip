@@ -38,6 +38,30 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
     return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 }
 
+// Per-pixel state of the blend, kept in SCALAR registers: a packed FP32 instruction costs the issue cycles of two scalar
+// ones on MI355X (tools/valu_microbench.hip), so nothing is lost by not packing, and a step that touches only ONE of
+// a lane's two pixels costs half.
+struct PixState { float T, Cr, Cg, Cb, D, acc; uint32_t last; bool done; };
+
+__device__ __forceinline__ void fwd_pixel(PixState& p, const float Ap, const float Bd, const float Cdd, const float dx,
+                                          const float op, const float cr, const float cg, const float cb, const float depth,
+                                          const uint32_t pos1)
+{
+    const float power = gauss_power1(Ap, Bd, Cdd, dx);
+    const float alpha = fminf(0.99f, op * __expf(power));
+    const float test_T = p.T * (1.0f - alpha);
+    // reference order of tests (forward.cu:331-347): power > 0 -> skip; alpha < 1/255 -> skip;
+    // T*(1-alpha) < 1e-4 -> pixel done (this Gaussian is NOT blended)
+    const bool pass = !p.done && power <= 0.0f && alpha >= 1.0f / 255.0f;
+    const bool stop = pass && test_T < 0.0001f;
+    const bool use = pass != stop;                                      // stop implies pass
+    p.done = p.done || stop;
+    const float wgt = use ? alpha * p.T : 0.f;
+    p.Cr += cr * wgt; p.Cg += cg * wgt; p.Cb += cb * wgt; p.D += depth * wgt; p.acc += wgt;
+    p.T = use ? test_T : p.T;
+    p.last = use ? pos1 : p.last;
+}
+
 __global__ void __launch_bounds__(BATCH)
 k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
@@ -58,18 +82,15 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y + w * 8;          // this wave's 16x8 box
     const int pxA = x0 + (l & 7), pxB = pxA + 8, py = y0 + (l >> 3);
     const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
-    const v2f pxf = { (float)pxA, (float)pxB };
+    const float pxfA = (float)pxA, pxfB = (float)pxB;
     const float pyf = (float)py;
     const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
-    v2f T = { 1.0f, 1.0f };
-    v2f Cr = { 0.f, 0.f }, Cg = Cr, Cb = Cr, Dacc = Cr, acc = { 0.000001f, 0.000001f };
-    uint32_t lastA = 0, lastB = 0;
-    bool doneA = !insA, doneB = !insB;
-    bool wave_done = __ballot(!doneA || !doneB) == 0;
+    PixState A = { 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u, !insA }, B = { 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u, !insB };
+    bool wave_done = __ballot(!A.done || !B.done) == 0;
 
     for (int base = 0; base < total; base += BATCH) {
         // both half tiles finished?  (also the barrier that protects the LDS planes of the previous batch)
@@ -90,19 +111,24 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         if (wave_done) continue;
 
         for (int sb = 0; sb < cnt; sb += 64) {
-            // CULL: lane l tests staged Gaussian sb+l against this wave's 16x8 box
-            bool hit = false;
+            // CULL: lane l tests staged Gaussian sb+l against the two 8x8 quadrants of this wave's 16x8 box (pixel A of
+            // every lane lies in the left quadrant, pixel B in the right one)
+            bool hitL = false, hitR = false;
             {
                 const int j = sb + l;
                 if (j < cnt) {
                     const float4 a = s_q0[j];
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    hit = box_hit(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * b.x, r.x, r.y, b.y, bx0, bx1, by0, by1);   // exact inverses
+                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
+                    hitL = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0, bx0 + 7.0f, by0, by1);
+                    hitR = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0 + 8.0f, bx1, by0, by1);
                 }
             }
-            uint64_t mask = __ballot(hit);
-            // BLEND: walk the candidates in list order; two pixels per lane, packed, branch-free
+            const uint64_t maskL = __ballot(hitL), maskR = __ballot(hitR);
+            uint64_t mask = maskL | maskR;
+            // BLEND: walk the candidates in list order; a candidate that missed a quadrant skips that pixel of every lane
+            // (exactly the reference's `continue`: no pixel there can reach alpha >= 1/255)
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
@@ -110,53 +136,34 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float4 a = s_q0[j];
                 const float4 b = s_q1[j];
                 const float4 c = s_q2[j];
-                const v2f dx = a.x - pxf;
-                const float dy = a.y - pyf;
-                const v2f power = gauss_power(a.z, a.w, b.x, dx, dy);
-                const v2f G = { __expf(power.x), __expf(power.y) };
-                const v2f alpha = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, b.z * G);
-                const v2f test_T = T * (1.0f - alpha);
-                // reference order of tests (forward.cu:331-347): power > 0 -> skip; alpha < 1/255 -> skip;
-                // T*(1-alpha) < 1e-4 -> pixel done (this Gaussian is NOT blended)
-                const bool passA = !doneA && power.x <= 0.0f && alpha.x >= 1.0f / 255.0f;
-                const bool passB = !doneB && power.y <= 0.0f && alpha.y >= 1.0f / 255.0f;
-                const bool stopA = passA && test_T.x < 0.0001f;
-                const bool stopB = passB && test_T.y < 0.0001f;
-                doneA = doneA || stopA;
-                doneB = doneB || stopB;
-                const bool useA = passA != stopA, useB = passB != stopB;     // stop implies pass: xor of the lane masks
-                const v2f wgt = { useA ? alpha.x * T.x : 0.f, useB ? alpha.y * T.y : 0.f };
-                Cr += c.x * wgt; Cg += c.y * wgt; Cb += c.z * wgt;
-                Dacc += b.w * wgt;
-                acc += wgt;
-                T.x = useA ? test_T.x : T.x;
-                T.y = useB ? test_T.y : T.y;
                 const uint32_t pos1 = (uint32_t)(base + j + 1);
-                lastA = useA ? pos1 : lastA;
-                lastB = useB ? pos1 : lastB;
+                const float dy = a.y - pyf;
+                const float Bd = a.w * dy, Cdd = (b.x * dy) * dy;                              // common.h gauss_power
+                if ((maskL >> k) & 1ull) fwd_pixel(A, a.z, Bd, Cdd, a.x - pxfA, b.z, c.x, c.y, c.z, b.w, pos1);
+                if ((maskR >> k) & 1ull) fwd_pixel(B, a.z, Bd, Cdd, a.x - pxfB, b.z, c.x, c.y, c.z, b.w, pos1);
             }
-            if (__ballot(!doneA || !doneB) == 0) { wave_done = true; break; }   // all 128 pixels are finished
+            if (__ballot(!A.done || !B.done) == 0) { wave_done = true; break; }   // all 128 pixels are finished
         }
     }
 
     const size_t N = (size_t)W * H;
     if (insA) {
         const size_t pix = (size_t)py * W + pxA;
-        final_T[pix] = T.x;
-        n_contrib[pix] = lastA;
-        out_color[pix] = Cr.x + T.x * bg[0];
-        out_color[N + pix] = Cg.x + T.x * bg[1];
-        out_color[2 * N + pix] = Cb.x + T.x * bg[2];
-        out_depth[pix] = (acc.x > 0.5f) ? Dacc.x / acc.x : 0.0f;         // forward.cu:384-388
+        final_T[pix] = A.T;
+        n_contrib[pix] = A.last;
+        out_color[pix] = A.Cr + A.T * bg[0];
+        out_color[N + pix] = A.Cg + A.T * bg[1];
+        out_color[2 * N + pix] = A.Cb + A.T * bg[2];
+        out_depth[pix] = (A.acc > 0.5f) ? A.D / A.acc : 0.0f;         // forward.cu:384-388
     }
     if (insB) {
         const size_t pix = (size_t)py * W + pxB;
-        final_T[pix] = T.y;
-        n_contrib[pix] = lastB;
-        out_color[pix] = Cr.y + T.y * bg[0];
-        out_color[N + pix] = Cg.y + T.y * bg[1];
-        out_color[2 * N + pix] = Cb.y + T.y * bg[2];
-        out_depth[pix] = (acc.y > 0.5f) ? Dacc.y / acc.y : 0.0f;
+        final_T[pix] = B.T;
+        n_contrib[pix] = B.last;
+        out_color[pix] = B.Cr + B.T * bg[0];
+        out_color[N + pix] = B.Cg + B.T * bg[1];
+        out_color[2 * N + pix] = B.Cb + B.T * bg[2];
+        out_depth[pix] = (B.acc > 0.5f) ? B.D / B.acc : 0.0f;
     }
 }
 
