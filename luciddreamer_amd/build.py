@@ -26,7 +26,7 @@ SOURCES = {
     "binning.hip": [],
     # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
     "render_fwd.hip": ["-fno-slp-vectorize"],
-    "render_bwd.hip": [],
+    "render_bwd.hip": ["-fno-slp-vectorize"],
     "gauss_bwd.hip": [],
     "knn.hip": [],
     "loss.hip": [],

@@ -94,12 +94,55 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 // s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
 // 8 db; the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
 //
-// 128 threads = 2 wave64 per 16x16 tile; a wave owns a 16x8 half tile, a lane owns TWO pixels (same row, 8
-// columns apart) and all per-pixel arithmetic is packed FP32 on 2-vectors.  The blend recursion is
-// branch-free: a pixel for which the Gaussian is skipped processes it as a layer with alpha = 0 and G = 0,
-// which leaves T, accum_rec and every gradient term exactly unchanged (T * rcp(1-0) = T; the colour
-// recursion folds the previous contributor in once, then passes it through with weight 1).
-// 7 waves per SIMD (<= 72 VGPRs): measured 2 % faster than the 78 registers / 6 waves the compiler picks, 8 is slower
+// 128 threads = 2 wave64 per 16x16 tile; a wave owns a 16x8 half tile, a lane owns TWO pixels (same row, 8 columns
+// apart: pixel A in the left 8x8 quadrant of the wave's box, pixel B in the right one).  Per-pixel state lives in
+// SCALAR registers: a packed FP32 instruction costs the issue cycles of two scalar ones on MI355X
+// (tools/valu_microbench.hip), so nothing is lost by not packing, and a candidate that failed the exact box test of one
+// quadrant (48 % of them) steps only the other pixel -- half the per-pixel work.  The recursion is branch-free per
+// pixel: a pixel for which the Gaussian is skipped processes it as a layer with alpha = 0 and G = 0, which leaves T,
+// the colour recursion and every gradient term exactly unchanged (T * rcp(1-0) = T; the recursion folds the previous
+// contributor in once, then passes it through with weight 1).
+struct BwdPix {
+    float T;            // transmittance in front of the current layer
+    float A;            // (colour seen BEHIND the current layer, background included) . dL/dpixel
+    float last_alpha;   // alpha of the previous (deeper) processed layer ...
+    float lcdl;         // ... and its colour . dL/dpixel
+    float dLr, dLg, dLb;
+    float pxf;
+    uint32_t last;      // index of the pixel's last contributor (n_contrib)
+};
+
+// One layer for one pixel; adds the pixel's terms to the lane sums.  Only what varies per pixel is formed here: the
+// colour recursion of backward.cu:517-533 enters only through its dot product with the pixel's dL/dpixel (constant along
+// the list), so ONE scalar A replaces three accumulators, and the background term -T_final/(1-alpha) * bg.dL
+// (backward.cu:556-560) is the last layer of the same recursion (A starts at bg.dL); of the geometric gradients only the
+// moments of D = G * dL/dalpha (D, D dx, D dx^2 here; the dy factors and opacity, conic, -0.5, NDC scale later).
+__device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float Bd, const float Cdd, const float gx,
+                                          const float op, const float cr, const float cg, const float cb, const uint32_t pos,
+                                          float& sD, float& sMx, float& sMxx, float& sR, float& sG, float& sB)
+{
+    const float dx = gx - p.pxf;
+    const float power = gauss_power1(Ap, Bd, Cdd, dx);
+    const float Graw = __expf(power);
+    const float araw = fminf(0.99f, op * Graw);
+    // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped
+    const bool v = pos < p.last && power <= 0.0f && araw >= 1.0f / 255.0f;
+    const float alpha = v ? araw : 0.f;
+    const float G = v ? Graw : 0.f;
+    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);                 // one v_rcp per pixel
+    p.T = p.T * rinv;
+    const float dchan = alpha * p.T;
+    const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;                // colour of this Gaussian . dL/dpixel
+    p.A = p.A + p.last_alpha * (p.lcdl - p.A);                             // = last_alpha * lcdl + (1 - last_alpha) * A
+    p.lcdl = cdl;
+    p.last_alpha = alpha;
+    const float dop = G * ((cdl - p.A) * p.T);                             // G * dL/dalpha
+    const float mx = dop * dx;
+    sD += dop; sMx += mx; sMxx += mx * dx;
+    sR += dchan * p.dLr; sG += dchan * p.dLg; sB += dchan * p.dLb;
+}
+
+// 7 waves per SIMD (<= 72 VGPRs)
 __global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
@@ -107,14 +150,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
              char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
 {
-    // Per-Gaussian constants are staged as DUPLICATED pairs {v, v}: the blend math is packed FP32 on 2-pixel vectors and a
-    // scalar operand that sits in an odd register (or must be broadcast) costs a v_mov per use in this VALU-issue-bound
-    // loop; a ds_read of a ready-made pair costs no VALU slot.
-    __shared__ float4 s_b0[BATCH];      // x, x, y, y
-    __shared__ float4 s_b1[BATCH];      // Ap = -0.5 conic a, Ap, Bp = -conic b, Bp     (common.h gauss_power)
-    __shared__ float4 s_b2[BATCH];      // Cp = -0.5 conic c, Cp, opacity, opacity
-    __shared__ float4 s_b3[BATCH];      // r, r, g, g
-    __shared__ float4 s_b4[BATCH];      // b, b, qmax (cull threshold), -
+    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, qmax (cull threshold), opacity, -
+    __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
     __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (both waves add into it)
@@ -127,7 +165,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y + w * 8;          // this wave's 16x8 box
     const int pxA = x0 + (l & 7), pxB = pxA + 8, py = y0 + (l >> 3);
     const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
-    const v2f pxf = { (float)pxA, (float)pxB };
     const float pyf = (float)py;
     const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
     const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
@@ -141,19 +178,18 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
 
-    const v2f T_final = { insA ? final_Ts[pixA] : 0.f, insB ? final_Ts[pixB] : 0.f };
-    v2f T = T_final;
-    const uint32_t lastA = insA ? n_contrib[pixA] : 0u, lastB = insB ? n_contrib[pixB] : 0u;
-    const uint32_t wave_last = wave_max_u32(max(lastA, lastB));     // nothing at or behind this matters to the wave
-    v2f dLr = { 0.f, 0.f }, dLg = dLr, dLb = dLr;
-    if (insA) { dLr.x = dL_dpix[pixA]; dLg.x = dL_dpix[N + pixA]; dLb.x = dL_dpix[2 * N + pixA]; }
-    if (insB) { dLr.y = dL_dpix[pixB]; dLg.y = dL_dpix[N + pixB]; dLb.y = dL_dpix[2 * N + pixB]; }
-    const v2f bgdl = bg[0] * dLr + bg[1] * dLg + bg[2] * dLb;                 // background . dL/dpixel
-    // A = (colour seen BEHIND the current layer, background included) . dL/dpixel.  The reference keeps the background in
-    // a separate term, -T_final/(1-alpha) * bg.dL (backward.cu:556-560); T_final/(1-alpha_i) = T_i * prod_{j>i}(1-alpha_j),
-    // i.e. the background is simply the last layer of the same recursion: start A at bg.dL instead of 0.
-    v2f A = bgdl;
-    v2f last_alpha = { 0.f, 0.f }, lcdl = last_alpha;  // alpha and (colour . dL/dpixel) of the previous layer
+    BwdPix PA, PB;
+    PA.pxf = (float)pxA; PB.pxf = (float)pxB;
+    PA.T = insA ? final_Ts[pixA] : 0.f; PB.T = insB ? final_Ts[pixB] : 0.f;
+    PA.last = insA ? n_contrib[pixA] : 0u; PB.last = insB ? n_contrib[pixB] : 0u;
+    PA.dLr = PA.dLg = PA.dLb = 0.f; PB.dLr = PB.dLg = PB.dLb = 0.f;
+    if (insA) { PA.dLr = dL_dpix[pixA]; PA.dLg = dL_dpix[N + pixA]; PA.dLb = dL_dpix[2 * N + pixA]; }
+    if (insB) { PB.dLr = dL_dpix[pixB]; PB.dLg = dL_dpix[N + pixB]; PB.dLb = dL_dpix[2 * N + pixB]; }
+    PA.A = bg[0] * PA.dLr + bg[1] * PA.dLg + bg[2] * PA.dLb;       // background . dL/dpixel: the deepest layer
+    PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
+    PA.last_alpha = PA.lcdl = 0.f; PB.last_alpha = PB.lcdl = 0.f;
+    const uint32_t lastL = wave_max_u32(PA.last), lastR = wave_max_u32(PB.last);   // per quadrant
+    const uint32_t wave_last = max(lastL, lastR);                   // nothing at or behind this matters to the wave
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
 
@@ -188,11 +224,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_b0[tid] = make_float4(a.x, a.x, a.y, a.y);
-            s_b1[tid] = make_float4(-0.5f * a.z, -0.5f * a.z, -a.w, -a.w);
-            s_b2[tid] = make_float4(-0.5f * b.x, -0.5f * b.x, b.y, b.y);
-            s_b3[tid] = make_float4(b.z, b.z, b.w, b.w);
-            s_b4[tid] = make_float4(c.x, c.x, c.z, 0.f);
+            s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
+            s_q1[tid] = make_float4(-0.5f * b.x, c.z, b.y, 0.f);
+            s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
         }
@@ -201,70 +235,42 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
-            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the wave's 16x8 box
-            bool hit = false;
+            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the two 8x8 quadrants of the
+            // wave's box, each with its own deepest last contributor
+            bool hitL = false, hitR = false;
             {
                 const int j = sb + l;
-                if (j < cnt && (uint32_t)(pos_hi - j) < wave_last) {
-                    const float4 a = s_b0[j];
-                    const float4 b = s_b1[j];
-                    const float4 c = s_b2[j];
-                    const float4 e = s_b4[j];
+                const uint32_t pos = (uint32_t)(pos_hi - j);
+                if (j < cnt && pos < wave_last) {
+                    const float4 a = s_q0[j];
+                    const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    hit = box_hit(a.x, a.z, -2.0f * b.x, -b.z, -2.0f * c.x, r.x, r.y, e.z, bx0, bx1, by0, by1);   // exact inverses
+                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
+                    hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0, bx0 + 7.0f, by0, by1);
+                    hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0 + 8.0f, bx1, by0, by1);
                 }
             }
-            uint64_t mask = __ballot(hit);
+            const uint64_t maskL = __ballot(hitL), maskR = __ballot(hitR);
+            uint64_t mask = maskL | maskR;
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
                 mask &= mask - 1;
                 const int j = sb + k;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
-                const float4 p0 = s_b0[j], p1 = s_b1[j], p2 = s_b2[j], p3 = s_b3[j];
-                const float4 p4 = s_b4[j];
-                const v2f gxv = { p0.x, p0.y };
-                const v2f op = { p2.z, p2.w }, cr = { p3.x, p3.y }, cg = { p3.z, p3.w };
-                const v2f cbl = { p4.x, p4.y };
-                const v2f dx = gxv - pxf;
-                const float dys = p0.z - pyf;                     // both pixels of a lane share the row
-                const v2f power = gauss_power(p1.x, p1.z, p2.x, dx, dys);
-                const v2f Graw = { __expf(power.x), __expf(power.y) };
-                const v2f araw = __builtin_elementwise_min(v2f{ 0.99f, 0.99f }, op * Graw);
-                // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0,
-                // alpha < 1/255  ->  skipped; here: processed as a layer with alpha = 0, G = 0
-                const bool vA = pos < lastA && power.x <= 0.0f && araw.x >= 1.0f / 255.0f;
-                const bool vB = pos < lastB && power.y <= 0.0f && araw.y >= 1.0f / 255.0f;
-                if (__ballot(vA || vB) == 0) continue;            // nothing in 128 pixels: state is unchanged
-                const v2f alpha = { vA ? araw.x : 0.f, vB ? araw.y : 0.f };
-                const v2f G = { vA ? Graw.x : 0.f, vB ? Graw.y : 0.f };
-                const v2f om = 1.0f - alpha;
-                const v2f rinv = { __builtin_amdgcn_rcpf(om.x), __builtin_amdgcn_rcpf(om.y) };   // one v_rcp per pixel
-                T = T * rinv;
-                const v2f dchan = alpha * T;
-                // The colour recursion of backward.cu:517-533 (accum_rec per channel, then sum over channels of
-                // (c - accum_rec) * dL/dpixel) only ever enters through its dot product with this pixel's dL/dpixel, which
-                // is constant along the list: carry A = accum_rec . dL instead of three accumulators.
-                const v2f cdl = cr * dLr + cg * dLg + cbl * dLb;  // colour of this Gaussian . dL/dpixel
-                A = A + last_alpha * (lcdl - A);                  // = last_alpha * lcdl + (1 - last_alpha) * A
-                lcdl = cdl;
-                last_alpha = alpha;
-                v2f dL_dalpha = cdl - A;
-                dL_dalpha = dL_dalpha * T;
-                // Per pixel only the moments of D = G * dL/dalpha are formed: D, D dx, D dy, D dx^2, D dx dy, D dy^2.
-                // The factors that are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of
-                // backward.cu:473-474) are applied once per instance when the batch is flushed.
-                const v2f dop = G * dL_dalpha;                    // G * dL/dalpha
-                // both pixels of a lane share dy, so the dy factors are applied to the lane's pair sums (scalar ops)
-                const v2f mx = dop * dx;
-                const v2f mxx = mx * dx;
-                const v2f t_dr = dchan * dLr, t_dg = dchan * dLg, t_db = dchan * dLb;
-                const float sD = dop.x + dop.y, sMx = mx.x + mx.y, sMxx = mxx.x + mxx.y;
+                const float4 a = s_q0[j];
+                const float4 b = s_q1[j];
+                const float4 c = s_q2[j];
+                const float dys = a.y - pyf;                      // both pixels of a lane share the row
+                const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
+                float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
+                if ((maskL >> k) & 1ull) bwd_pixel(PA, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if ((maskR >> k) & 1ull) bwd_pixel(PB, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
-                // the lane's two pixels add up first, then the wave reduction of the nine terms
                 float ra = reduce4(sMx, sMy, sMxx, sMxy);
-                float rb = reduce4(sMyy, sD, t_dr.x + t_dr.y, t_dg.x + t_dg.y);
-                float rc = row_sum(t_db.x + t_db.y);              // every row: its partial of db
+                float rb = reduce4(sMyy, sD, sR, sG);
+                float rc = row_sum(sB);                           // every row: its partial of db
                 // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
                 // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
                 asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
@@ -279,10 +285,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         __syncthreads();
         if (tid < cnt) {
             // every instance owns one 48-byte slot: plain stores, no atomics, and the per-Gaussian sum in
-            // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed)
+            // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed).  The factors that
+            // are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of backward.cu:473-474) go in here.
             const float* a9 = s_acc[tid];              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db
-            const float4 q1 = s_b1[tid], q2 = s_b2[tid];
-            const float ca = -2.0f * q1.x, cb = -q1.z, cc = -2.0f * q2.x, o = q2.z;
+            const float4 q0 = s_q0[tid], q1 = s_q1[tid];
+            const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.z;
             const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
