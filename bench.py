@@ -234,11 +234,14 @@ def main():
             if "SQ_INSTS_VALU" in pmc:
                 # the blend kernels are VALU bound: wave-instructions per launch from the PMC
                 # pass over this launch's measured duration.  Reference rates (tools/valu_microbench.hip on MI355X):
-                # 912 G wave-instr/s for v_fma_f32, 453 G/s for v_pk_fma_f32; "peak" below is 256 CUs x 4 SIMDs x
-                # one issue per 4 cycles at 2.4 GHz, the rate of an all-packed instruction stream
+                # 912 G wave-instr/s for v_fma_f32, 453 G/s for v_pk_fma_f32
                 ginst = pmc["SQ_INSTS_VALU"] / dom_avg_s / 1e9
                 valu = {"wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_ginst_s": round(ginst, 1),
-                        "peak_ginst_s": 614.4, "frac": round(ginst / 614.4, 4)}
+                        "reference_ginst_s": {"v_fma_f32": 912.0, "v_pk_fma_f32": 453.0}}
+                if "SQ_ACTIVE_INST_VALU" in pmc:
+                    # cycles in which a SIMD's VALU was executing (counter is in units of 4 cycles, summed over the
+                    # 1024 SIMDs) over the cycles of this launch at the 2.4 GHz peak clock
+                    valu["valu_busy_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * dom_avg_s * 2.4e9), 4)
         except (OSError, ValueError):
             traffic = None
     roofline = {
