@@ -24,6 +24,14 @@ __global__ void __launch_bounds__(256) k(float* out, float seed, int iters)
             if (MODE == 0) a[i] = __builtin_fmaf(a[i], m, c);
             if (MODE == 1) p[i] = __builtin_elementwise_fma(p[i], v2f{ m, m }, v2f{ c, c });
             if (MODE == 2) a[i] = __expf(a[i] * 1e-9f);
+            if (MODE == 3) a[i] = __builtin_amdgcn_exp2f(a[i]);                          // v_exp_f32 alone
+            if (MODE == 4) a[i] = __builtin_amdgcn_rcpf(a[i]);                           // v_rcp_f32
+            if (MODE == 5) a[i] = fminf(a[i], m);                                        // v_min_f32
+            if (MODE == 6) a[i] = (a[i] < c) ? m : a[i];                                 // v_cmp + v_cndmask
+            if (MODE == 7) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0xB1, 0xf, 0xf, false));  // v_add_f32_dpp
+            if (MODE == 9) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, a[i]), 0x041F));   // xor 1 via the LDS crossbar + v_add
+            if (MODE == 10) a[i] += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a[i]), 0xB1, 0xf, 0xf, false)) * m;   // v_mov_dpp + v_fma
+            if (MODE == 8) { float y = a[(i + 1) % UNROLL]; asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(y)); a[(i + 1) % UNROLL] = y; }
         }
     }
     float s = 0.f;
@@ -45,7 +53,7 @@ void run(const char* name, float* d)
     hipEventSynchronize(e1);
     float ms = 0.f;
     hipEventElapsedTime(&ms, e0, e1);
-    const double insts = (double)blocks * 4 /*waves*/ * ITERS * UNROLL * (MODE == 2 ? 2 : 1);
+    const double insts = (double)blocks * 4 /*waves*/ * ITERS * UNROLL * ((MODE == 2 || MODE == 6 || MODE == 9 || MODE == 10) ? 2 : 1);
     const double gps = insts / (ms * 1e-3) / 1e9;
     printf("%s: %.3f ms, %.2f G wave-instr/s, per-SIMD cycles/instr at 2.4GHz = %.2f\n", name, ms, gps, 1024 * 2.4 / gps);
 }
@@ -57,5 +65,13 @@ int main()
     run<0>("v_fma_f32", d);
     run<1>("v_pk_fma_f32", d);
     run<2>("v_exp_f32(+mul)", d);
+    run<3>("v_exp_f32", d);
+    run<4>("v_rcp_f32", d);
+    run<5>("v_min_f32", d);
+    run<6>("v_cmp+v_cndmask", d);
+    run<7>("v_add_f32_dpp", d);
+    run<8>("v_permlane32_swap (+s_nop 1)", d);
+    run<9>("ds_swizzle + v_add_f32", d);
+    run<10>("v_mov_dpp + v_fma", d);
     return 0;
 }
