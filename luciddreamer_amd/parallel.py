@@ -45,7 +45,10 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = device
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        except TypeError:                          # a torch without the device_id keyword
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, device
 
 
