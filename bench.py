@@ -59,8 +59,8 @@ def path_bytes(P, V, R, N, T, K, M):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c3box"])
     ap.add_argument("--views", type=int, default=None, help="views per rank per step")
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
