@@ -2,10 +2,10 @@
 // gradient all-reduce of the data-parallel step; torch.optim.Adam(l, lr=0.0, eps=1e-15) in
 // R/scene/gaussian_model.py:165 with one param group, hence one learning rate, per tensor).
 //
-// torch's default (foreach) Adam runs ~10 elementwise kernels per step over every tensor; this is one pass:
-// 16 B read + 12 B written per element... per element: param, grad, exp_avg, exp_avg_sq read (16 B), param, exp_avg,
-// exp_avg_sq written (12 B).  Same formula and operation order as torch's single-tensor implementation
-// (torch/optim/adam.py _single_tensor_adam, no weight decay, no amsgrad, maximize=False):
+// torch's default (foreach) Adam runs ~10 elementwise kernels per step over every tensor; this is one pass that reads
+// param, grad, exp_avg, exp_avg_sq (16 B per element) and writes param, exp_avg, exp_avg_sq (12 B).  Same formula and
+// operation order as torch's single-tensor implementation (torch/optim/adam.py _single_tensor_adam, no weight decay, no
+// amsgrad, maximize=False):
 //   exp_avg    <- exp_avg + (1 - beta1) * (grad - exp_avg)                      (lerp_)
 //   exp_avg_sq <- beta2 * exp_avg_sq + (1 - beta2) * grad * grad              (mul_, addcmul_)
 //   denom      <- sqrt(exp_avg_sq) / sqrt(1 - beta2^t) + eps
