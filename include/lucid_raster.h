@@ -261,6 +261,27 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
                    void* stream);
 
 /*
+ * The same multi-view step with the photometric loss inside (render -> L1 + DSSIM against a target -> backward, per
+ * view, on the view's stream): the per-iteration body of the training loop, R/luciddreamer.py:296-304, for n_views
+ * views of one parameter set.  targets[v]: [3,H,W] device images; out_losses: device float[3 * n_views] receiving
+ * {loss, l1, ssim} per view; gradients of sum_v loss_v are accumulated into the acc_* buffers (SH colours and
+ * scale/rotation covariances only).  Workspace from lr_views_train_workspace_bytes; overflow check with
+ * lr_views_train_check.  No host synchronisation.
+ */
+size_t lr_views_train_workspace_bytes(int P, int width, int height, long long binning_capacity, int n_streams);
+int lr_views_train_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+                              const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
+                              int P, int D, int M, const float* background, int width, int height,
+                              const float* means3D, const float* shs, const float* opacities, const float* scales,
+                              float scale_modifier, const float* rotations, const float* const* targets,
+                              float lambda_dssim, float* out_losses, float* const* out_color, int* const* out_radii,
+                              float* acc_mean2D, float* acc_opacity, float* acc_mean3D, float* acc_sh, float* acc_scale,
+                              float* acc_rot, char* workspace, size_t workspace_bytes, long long binning_capacity,
+                              int n_streams, void* stream);
+int lr_views_train_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                         void* stream);
+
+/*
  * Row surgery of the Gaussian parameter set.  The reference changes the number of Gaussians
  * with boolean-mask indexing / torch.cat applied tensor by tensor to the six parameters and both Adam moments of
  * each (R/scene/gaussian_model.py:273-340 prune_points, _prune_optimizer, cat_tensors_to_optimizer; :342-403

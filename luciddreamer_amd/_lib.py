@@ -28,7 +28,8 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward",
-           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats")
+           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats",
+           "lr_views_train_workspace_bytes", "lr_views_train_accumulate", "lr_views_train_check")
 
 
 def lib():
@@ -100,6 +101,17 @@ def lib():
                                           vp, ctypes.c_size_t, ll, ci, vp]       # workspace, bytes, capacity, n_streams, stream
         L.lr_views_check.restype = ci
         L.lr_views_check.argtypes = [vp, ci, ci, ci, ll, ci, vp]
+        L.lr_views_train_workspace_bytes.restype = ctypes.c_size_t
+        L.lr_views_train_workspace_bytes.argtypes = [ci, ci, ci, ll, ci]
+        L.lr_views_train_accumulate.restype = ci
+        L.lr_views_train_accumulate.argtypes = [ci, vp, vp, vp, vp, vp,          # n_views, view/proj/campos arrays, tanfovx/y arrays
+                                                ci, ci, ci, vp, ci, ci,          # P D M bg W H
+                                                vp, vp, vp, vp, cf, vp,          # means3D shs opac scales mod rot
+                                                vp, cf, vp, vp, vp,              # targets[], lambda, out_losses, out_color[], out_radii[]
+                                                vp, vp, vp, vp, vp, vp,          # 6 accumulators
+                                                vp, ctypes.c_size_t, ll, ci, vp] # workspace, bytes, capacity, n_streams, stream
+        L.lr_views_train_check.restype = ci
+        L.lr_views_train_check.argtypes = [vp, ci, ci, ci, ll, ci, vp]
         L.lr_loss_workspace_bytes.restype = ctypes.c_size_t
         L.lr_loss_workspace_bytes.argtypes = [ci, ci, ci]
         L.lr_l1_dssim_forward.restype = ci

@@ -417,8 +417,8 @@ int lr_backward_raw(int P, int D, int M, int R, const float* background, int wid
 // ---------------------------------------------------------------------------------------------------
 namespace {
 constexpr int kMaxViewStreams = 4;
-struct ViewSlot { size_t geom, img, bin, color, depth, radii, total; };
-ViewSlot view_slot_layout(int P, int W, int H, long long capacity)
+struct ViewSlot { size_t geom, img, bin, color, depth, radii, loss_ws, grad_img, total; };
+ViewSlot view_slot_layout(int P, int W, int H, long long capacity, bool with_loss = false)
 {
     ViewSlot L; size_t o = 0;
     const size_t N = (size_t)W * H;
@@ -428,6 +428,8 @@ ViewSlot view_slot_layout(int P, int W, int H, long long capacity)
     L.color = o; o += lr::align_up(3 * N * 4);
     L.depth = o; o += lr::align_up(N * 4);
     L.radii = o; o += lr::align_up((size_t)(P > 0 ? P : 1) * 4);
+    L.loss_ws = o;  if (with_loss) o += lr::align_up(lr::loss_workspace_bytes(3, H, W));
+    L.grad_img = o; if (with_loss) o += lr::align_up(3 * N * 4);
     L.total = o;
     return L;
 }
@@ -448,7 +450,7 @@ size_t lr_views_workspace_bytes(int P, int width, int height, long long binning_
     return view_slot_layout(P, width, height, binning_capacity).total * (size_t)n_streams;
 }
 
-int lr_views_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+static int views_core(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
                         const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
                         int P, int D, int M, const float* background, int width, int height,
                         const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
@@ -457,19 +459,21 @@ int lr_views_accumulate(int n_views, const float* const* viewmatrices, const flo
                         float* acc_mean2D, float* acc_opacity, float* acc_color, float* acc_mean3D, float* acc_cov3D,
                         float* acc_sh, float* acc_scale, float* acc_rot,
                         char* workspace, size_t workspace_bytes, long long binning_capacity, int n_streams,
-                        void* stream_)
+                        void* stream_, const float* const* targets, float lambda_dssim, float* out_losses)
 {
     using namespace lr;
+    const bool with_loss = targets != nullptr;
     hipStream_t caller = reinterpret_cast<hipStream_t>(stream_);
     if (n_views <= 0 || P <= 0) return 0;
     if (binning_capacity <= 0) return fail(LR_ERR_INVALID_ARG, "lr_views_accumulate runs in async mode: binning_capacity > 0 is required");
-    if (!viewmatrices || !projmatrices || !cam_positions || !tan_fovx || !tan_fovy || !dL_dpix || !workspace)
+    if (!viewmatrices || !projmatrices || !cam_positions || !tan_fovx || !tan_fovy || (!dL_dpix && !with_loss) || !workspace)
         return fail(LR_ERR_INVALID_ARG, "per-view arrays and workspace are required");
+    if (with_loss && !out_losses) return fail(LR_ERR_INVALID_ARG, "out_losses is required with targets");
     if (!acc_mean2D || !acc_opacity || !acc_mean3D) return fail(LR_ERR_INVALID_ARG, "acc_mean2D/acc_opacity/acc_mean3D are required");
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
     if (n_streams > n_views) n_streams = n_views;
-    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity);
+    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity, with_loss);
     if (workspace_bytes < SL.total * (size_t)n_streams) return fail(LR_ERR_INVALID_ARG, "workspace too small (lr_views_workspace_bytes)");
 
     for (int i = 0; i < n_streams; i++)
@@ -510,10 +514,19 @@ int lr_views_accumulate(int n_views, const float* const* viewmatrices, const flo
                             viewmatrices[v], projmatrices[v], cam_positions[v], tan_fovx[v], tan_fovy[v], 0, color, depth,
                             radii, 0, binning_capacity, s);
         if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) return rc;
+        const float* view_grad = with_loss ? nullptr : dL_dpix[v];
+        if (with_loss) {
+            // the photometric loss of this view against its target and dL/dcolor, on the same stream
+            // (R/luciddreamer.py:301-304); out_losses[3 v .. 3 v + 2] = {loss, l1, ssim}
+            float* gimg = reinterpret_cast<float*>(slot + SL.grad_img);
+            launch_loss_forward(3, height, width, color, targets[v], lambda_dssim, out_losses + 3 * (size_t)v, slot + SL.loss_ws, s);
+            launch_loss_backward(3, height, width, color, targets[v], lambda_dssim, nullptr, slot + SL.loss_ws, gimg, s);
+            view_grad = gimg;
+        }
         rc = backward_core(P, D, M, LR_NUM_RENDERED_ON_DEVICE, background, width, height, means3D, shs, colors_precomp,
                            scales, scale_modifier, rotations, cov3D_precomp, viewmatrices[v], projmatrices[v],
                            cam_positions[v], tan_fovx[v], tan_fovy[v], radii, slot + SL.geom, slot + SL.bin, slot + SL.img,
-                           dL_dpix[v], nullptr, acc_mean2D, nullptr, acc_opacity, acc_color, acc_mean3D, acc_cov3D, acc_sh,
+                           view_grad, nullptr, acc_mean2D, nullptr, acc_opacity, acc_color, acc_mean3D, acc_cov3D, acc_sh,
                            acc_scale, acc_rot, 0, binning_capacity, mask, s, prev);
         if (rc < 0) return rc;
         hipEvent_t done = ev_bwd[v % (n_streams + 1)];
@@ -527,15 +540,58 @@ int lr_views_accumulate(int n_views, const float* const* viewmatrices, const flo
     return 0;
 }
 
-int lr_views_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
-                   void* stream_)
+int lr_views_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+                        const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
+                        int P, int D, int M, const float* background, int width, int height,
+                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* const* dL_dpix, float* const* out_color, int* const* out_radii,
+                        float* acc_mean2D, float* acc_opacity, float* acc_color, float* acc_mean3D, float* acc_cov3D,
+                        float* acc_sh, float* acc_scale, float* acc_rot,
+                        char* workspace, size_t workspace_bytes, long long binning_capacity, int n_streams,
+                        void* stream_)
+{
+    return views_core(n_views, viewmatrices, projmatrices, cam_positions, tan_fovx, tan_fovy, P, D, M, background, width,
+                      height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                      dL_dpix, out_color, out_radii, acc_mean2D, acc_opacity, acc_color, acc_mean3D, acc_cov3D, acc_sh,
+                      acc_scale, acc_rot, workspace, workspace_bytes, binning_capacity, n_streams, stream_, nullptr, 0.f,
+                      nullptr);
+}
+
+size_t lr_views_train_workspace_bytes(int P, int width, int height, long long binning_capacity, int n_streams)
+{
+    if (n_streams < 1) n_streams = 1;
+    if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
+    return view_slot_layout(P, width, height, binning_capacity, true).total * (size_t)n_streams;
+}
+
+int lr_views_train_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
+                              const float* const* cam_positions, const float* tan_fovx, const float* tan_fovy,
+                              int P, int D, int M, const float* background, int width, int height,
+                              const float* means3D, const float* shs, const float* opacities, const float* scales,
+                              float scale_modifier, const float* rotations, const float* const* targets,
+                              float lambda_dssim, float* out_losses, float* const* out_color, int* const* out_radii,
+                              float* acc_mean2D, float* acc_opacity, float* acc_mean3D, float* acc_sh, float* acc_scale,
+                              float* acc_rot, char* workspace, size_t workspace_bytes, long long binning_capacity,
+                              int n_streams, void* stream_)
+{
+    if (!targets) return fail(LR_ERR_INVALID_ARG, "targets are required");
+    return views_core(n_views, viewmatrices, projmatrices, cam_positions, tan_fovx, tan_fovy, P, D, M, background, width,
+                      height, means3D, shs, nullptr, opacities, scales, scale_modifier, rotations, nullptr, nullptr,
+                      out_color, out_radii, acc_mean2D, acc_opacity, nullptr, acc_mean3D, nullptr, acc_sh, acc_scale,
+                      acc_rot, workspace, workspace_bytes, binning_capacity, n_streams, stream_, targets, lambda_dssim,
+                      out_losses);
+}
+
+static int views_check_core(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                            void* stream_, bool with_loss)
 {
     using namespace lr;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!workspace) return fail(LR_ERR_INVALID_ARG, "NULL workspace");
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
-    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity);
+    const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity, with_loss);
     uint32_t flags[kMaxViewStreams] = { 0, 0, 0, 0 };
     for (int i = 0; i < n_streams; i++) {
         const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
@@ -545,6 +601,18 @@ int lr_views_check(const char* workspace, int P, int width, int height, long lon
     for (int i = 0; i < n_streams; i++)
         if (flags[i]) return fail(LR_ERR_OVERFLOW, "binning capacity exceeded by at least one view of the step");
     return 0;
+}
+
+int lr_views_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                   void* stream_)
+{
+    return views_check_core(workspace, P, width, height, binning_capacity, n_streams, stream_, false);
+}
+
+int lr_views_train_check(const char* workspace, int P, int width, int height, long long binning_capacity, int n_streams,
+                         void* stream_)
+{
+    return views_check_core(workspace, P, width, height, binning_capacity, n_streams, stream_, true);
 }
 
 size_t lr_select_workspace_bytes(int P) { return lr::select_workspace_bytes(P); }

@@ -156,8 +156,12 @@ class ViewBatch:
           image_width, image_height (e.g. cameras.MiniCam); all views share one resolution.
     """
 
-    def __init__(self, cams: Sequence, grad_colors: Sequence[torch.Tensor], sh_degree: int, bg: torch.Tensor,
-                 binning_capacity: int, n_streams: int = 2, scale_modifier: float = 1.0):
+    def __init__(self, cams: Sequence, grad_colors: Optional[Sequence[torch.Tensor]], sh_degree: int, bg: torch.Tensor,
+                 binning_capacity: int, n_streams: int = 2, scale_modifier: float = 1.0,
+                 targets: Optional[Sequence[torch.Tensor]] = None, lambda_dssim: float = 0.2):
+        """grad_colors: fixed upstream gradients dL/dcolor per view, OR targets: ground-truth images per view, in which
+        case every view's L1 + DSSIM loss against its target is formed inside the call (lr_views_train_accumulate) and
+        `self.losses` ([n,3] device tensor: loss, l1, ssim per view) is filled by run()."""
         import ctypes
         import math
         from . import _lib
@@ -165,7 +169,9 @@ class ViewBatch:
         self.L = _lib.lib()
         self.cams = list(cams)
         self.n = len(self.cams)
-        assert self.n == len(grad_colors) and self.n > 0
+        if (grad_colors is None) == (targets is None):
+            raise ValueError("give exactly one of grad_colors / targets")
+        assert self.n == len(grad_colors if targets is None else targets) and self.n > 0
         self.W, self.H = int(self.cams[0].image_width), int(self.cams[0].image_height)
         self.device = self.cams[0].world_view_transform.device
         self.degree, self.scale_modifier = int(sh_degree), float(scale_modifier)
@@ -180,7 +186,10 @@ class ViewBatch:
         self._views = ptr_array([c.world_view_transform for c in self.cams])
         self._projs = ptr_array([c.full_proj_transform for c in self.cams])
         self._campos = ptr_array([c.camera_center for c in self.cams])
-        self._grads = ptr_array(grad_colors)
+        self.train = targets is not None
+        self.lambda_dssim = float(lambda_dssim)
+        self._grads = ptr_array(grad_colors if not self.train else targets)     # per-view dL/dcolor, or target images
+        self.losses = torch.zeros((self.n, 3), dtype=torch.float32, device=self.device) if self.train else None
         self._tanx = (ctypes.c_float * self.n)(*[math.tan(c.FoVx * 0.5) for c in self.cams])
         self._tany = (ctypes.c_float * self.n)(*[math.tan(c.FoVy * 0.5) for c in self.cams])
         self._keep = keep
@@ -193,13 +202,25 @@ class ViewBatch:
         P, M = int(means3D.shape[0]), int(shs.shape[1])
         key = (P, self.capacity)
         if self._ws_key != key:
-            nbytes = self.L.lr_views_workspace_bytes(P, self.W, self.H, self.capacity, self.n_streams)
+            size_fn = self.L.lr_views_train_workspace_bytes if self.train else self.L.lr_views_workspace_bytes
+            nbytes = size_fn(P, self.W, self.H, self.capacity, self.n_streams)
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
             self._ws_key = key
         for t in (means3D, opacities, scales, rotations, shs, *acc.values()):
             if not (t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()):
                 raise RuntimeError("ViewBatch.run needs contiguous float32 tensors on the HIP device")
         stream = torch.cuda.current_stream(self.device).cuda_stream
+        if self.train:
+            rc = self.L.lr_views_train_accumulate(
+                self.n, self._views, self._projs, self._campos, self._tanx, self._tany, P, self.degree, M,
+                self.bg.data_ptr(), self.W, self.H, means3D.data_ptr(), shs.data_ptr(), opacities.data_ptr(),
+                scales.data_ptr(), self.scale_modifier, rotations.data_ptr(), self._grads, self.lambda_dssim,
+                self.losses.data_ptr(), None, None, acc["means2D"].data_ptr(), acc["opacity"].data_ptr(),
+                acc["means3D"].data_ptr(), acc["sh"].data_ptr(), acc["scales"].data_ptr(), acc["rotations"].data_ptr(),
+                self._ws.data_ptr(), self._ws.numel(), self.capacity, self.n_streams, stream)
+            if rc < 0:
+                self._lib.raise_for(rc, "lr_views_train_accumulate")
+            return
         rc = self.L.lr_views_accumulate(
             self.n, self._views, self._projs, self._campos, self._tanx, self._tany, P, self.degree, M,
             self.bg.data_ptr(), self.W, self.H, means3D.data_ptr(), shs.data_ptr(), None, opacities.data_ptr(),
@@ -215,8 +236,9 @@ class ViewBatch:
         if self._ws is None:
             return
         P = self._ws_key[0]
-        rc = self.L.lr_views_check(self._ws.data_ptr(), P, self.W, self.H, self.capacity, self.n_streams,
-                                   torch.cuda.current_stream(self.device).cuda_stream)
+        check = self.L.lr_views_train_check if self.train else self.L.lr_views_check
+        rc = check(self._ws.data_ptr(), P, self.W, self.H, self.capacity, self.n_streams,
+                   torch.cuda.current_stream(self.device).cuda_stream)
         if rc < 0:
             self._lib.raise_for(rc, "lr_views_check")
 

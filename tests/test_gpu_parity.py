@@ -374,3 +374,49 @@ def test_view_batch_equals_autograd_accumulation(hip_device):
               leaf["rotations"].detach(), leaf["shs"].detach(), acc)
     with pytest.raises(RuntimeError, match="capacity"):
         small.check()
+
+
+def test_view_batch_with_fused_loss_equals_autograd(hip_device):
+    """ViewBatch(targets=...) (lr_views_train_accumulate: render -> L1+DSSIM -> backward per view inside one C call)
+    == the autograd op followed by luciddreamer_amd.loss.l1_dssim_loss, summed over the views."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import parallel
+    from luciddreamer_amd.loss import l1_dssim_loss
+    P, W, H = 20_000, 256, 160
+    cloud = synthetic.make_cloud(P, "band", 8)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(W, H, n_views=5)]
+    gen = torch.Generator().manual_seed(3)
+    targets = [torch.rand(3, H, W, generator=gen).to(hip_device) for _ in cams]
+    bg = torch.tensor([0.0, 0.1, 0.0], device=hip_device)
+    leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
+    m2d = torch.zeros(P, 3, device=hip_device, requires_grad=True)
+    losses = []
+    for c, tgt in zip(cams, targets):
+        tfx, tfy = hp.tan_fov(c)
+        rs = GaussianRasterizationSettings(H, W, tfx, tfy, bg, 1.0, c.world_view_transform, c.full_proj_transform,
+                                           3, c.camera_center, False, False)
+        col, _, _ = GaussianRasterizer(rs)(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                           shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+        loss = l1_dssim_loss(col, tgt, 0.2)
+        loss.backward()
+        losses.append(float(loss.detach()))
+    ref = {k: v.grad.clone() for k, v in leaf.items()}
+    ref["means2D"] = m2d.grad.clone()
+
+    acc = {"means3D": torch.zeros_like(leaf["means3D"]), "means2D": torch.zeros_like(m2d),
+           "opacity": torch.zeros_like(leaf["opacities"]), "sh": torch.zeros_like(leaf["shs"]),
+           "scales": torch.zeros_like(leaf["scales"]), "rotations": torch.zeros_like(leaf["rotations"])}
+    batch = parallel.ViewBatch(cams, None, 3, bg, binning_capacity=300_000, n_streams=3, targets=targets, lambda_dssim=0.2)
+    with torch.no_grad():
+        batch.run(leaf["means3D"].detach(), leaf["opacities"].detach(), leaf["scales"].detach(),
+                  leaf["rotations"].detach(), leaf["shs"].detach(), acc)
+    batch.check()
+    got = batch.losses.cpu().numpy()
+    assert np.abs(got[:, 0] - np.array(losses)).max() <= 1e-6
+    names = {"means3D": "means3D", "means2D": "means2D", "opacity": "opacities", "sh": "shs", "scales": "scales",
+             "rotations": "rotations"}
+    for k, rk in names.items():
+        a, b = acc[k].cpu().numpy(), ref[rk].cpu().numpy()
+        assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 2e-5 * np.abs(b).max(), k
+    with pytest.raises(ValueError):
+        parallel.ViewBatch(cams, None, 3, bg, binning_capacity=1000)
