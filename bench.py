@@ -68,9 +68,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--resolution", default="1920x1080", help="WxH (the metric uses 1920x1080)")
     ap.add_argument("--sh-degree", type=int, default=3, choices=[0, 1, 2, 3], help="active SH degree (diagnostics; the metric uses 3)")
-    ap.add_argument("--api", default="views", choices=["views", "autograd"],
+    ap.add_argument("--api", default="views", choices=["views", "autograd", "views-loss"],
                     help="views: one lr_views_accumulate call per step (parallel.ViewBatch); autograd: the drop-in "
-                         "GaussianRasterizer autograd op per view (parallel.ViewStreams)")
+                         "GaussianRasterizer autograd op per view (parallel.ViewStreams); views-loss: the views step with "
+                         "the fused L1+DSSIM loss against a target image formed inside (not the metric: extra work)")
     ap.add_argument("--streams", type=int, default=3,
                     help="HIP streams the views of a step alternate on (forward of view i+1 overlaps backward of view i)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
@@ -148,9 +149,13 @@ def main():
 
     pipe = parallel.ViewStreams(dev, args.streams)
     batch = None
-    if args.api == "views":
+    if args.api in ("views", "views-loss"):
         cap = int(max(s[0] for s in view_stats) * 1.25) + 4096
-        batch = parallel.ViewBatch(cams, [grad_color] * len(cams), degree, bg, cap, n_streams=args.streams)
+        if args.api == "views":
+            batch = parallel.ViewBatch(cams, [grad_color] * len(cams), degree, bg, cap, n_streams=args.streams)
+        else:
+            target = torch.rand(3, H, W, generator=torch.Generator().manual_seed(2)).to(dev)
+            batch = parallel.ViewBatch(cams, None, degree, bg, cap, n_streams=args.streams, targets=[target] * len(cams))
         acc = {"means3D": leaf["means3D"].grad, "means2D": m2d_grad, "opacity": leaf["opacities"].grad,
                "sh": leaf["shs"].grad, "scales": leaf["scales"].grad, "rotations": leaf["rotations"].grad}
 
