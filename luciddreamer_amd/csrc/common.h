@@ -249,6 +249,10 @@ void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* o
 void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long n_bound, int num_tiles,
                    uint2* ranges, hipStream_t s);
 
+// Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per
+// tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue
+// bound).  LR_BLEND_QUAD_BWD=0/1 forces one (diagnostics).
+bool blend_quad(int num_tiles);
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s);

@@ -18,15 +18,20 @@
 //                  -> ONE plain 48-byte store per tile instance into that instance's own slot
 //                     (inst_grad[emission index]); the slots of a Gaussian are contiguous and are summed,
 //                     in a fixed order, by k_gauss_bwd.  No global atomics at all, nothing to pre-zero.
+#include <cstdlib>
 #include "common.h"
 
 namespace lr {
 
 namespace {
 
-constexpr int BATCH = 64;           // staged Gaussians per round (64: 8 KB of LDS per workgroup, so registers -- 6 waves per
+#ifndef LR_QBATCH_BWD
+#define LR_QBATCH_BWD 256           // staging round of the QUAD shape: one Gaussian per thread
+#endif
+constexpr int BATCH2 = 64;          // staged Gaussians per round (64: 8 KB of LDS per workgroup, so registers -- 6 waves per
                                     // SIMD -- and not LDS limit the occupancy; measured 3 % faster than 128, 32 is slower)
-constexpr int THREADS = 128;        // threads per workgroup (2 wave64)
+                                    // threads per workgroup: 128 (2 wave64), or 256 with QUAD (one 8x8 quadrant per wave,
+                                    // one pixel per lane, as in the forward; chosen for small images by blend_quad below)
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp(float v)
@@ -143,28 +148,32 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
 }
 
 // 7 waves per SIMD (<= 72 VGPRs)
-__global__ void __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(7, 8)))
+template <bool QUAD>
+__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
              char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
 {
+    constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
     __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, qmax (cull threshold), opacity, -
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
     __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (both waves add into it)
-    __shared__ uint32_t s_wlast[2];
+    constexpr int NWAVES = QUAD ? 4 : 2;
+    __shared__ uint32_t s_wlast[NWAVES];
 
     const int tile = swizzled_tile(num_tiles);
     if (tile >= num_tiles) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int x0 = tx * TILE_X, y0 = ty * TILE_Y + w * 8;          // this wave's 16x8 box
+    // this wave's box: 16x8 (pixel A left, pixel B right quadrant), or with QUAD the 8x8 quadrant (w&1, w>>1), pixel A only
+    const int x0 = tx * TILE_X + (QUAD ? (w & 1) * 8 : 0), y0 = ty * TILE_Y + (QUAD ? (w >> 1) : w) * 8;
     const int pxA = x0 + (l & 7), pxB = pxA + 8, py = y0 + (l >> 3);
-    const bool insA = pxA < W && py < H, insB = pxB < W && py < H;
+    const bool insA = pxA < W && py < H, insB = !QUAD && pxB < W && py < H;
     const float pyf = (float)py;
     const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
     const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
@@ -188,7 +197,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     PA.A = bg[0] * PA.dLr + bg[1] * PA.dLg + bg[2] * PA.dLb;       // background . dL/dpixel: the deepest layer
     PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
     PA.last_alpha = PA.lcdl = 0.f; PB.last_alpha = PB.lcdl = 0.f;
-    const uint32_t lastL = wave_max_u32(PA.last), lastR = wave_max_u32(PB.last);   // per quadrant
+    const uint32_t lastL = wave_max_u32(PA.last), lastR = QUAD ? 0u : wave_max_u32(PB.last);   // per quadrant
     const uint32_t wave_last = max(lastL, lastR);                   // nothing at or behind this matters to the wave
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
@@ -196,7 +205,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     // block-uniform: the deepest contributor of any pixel in the tile; batches entirely behind it are skipped
     if (l == 0) s_wlast[w] = wave_last;
     __syncthreads();
-    const uint32_t tile_last = max(s_wlast[0], s_wlast[1]);
+    uint32_t tile_last = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVES; i++) tile_last = max(tile_last, s_wlast[i]);
 
     // LDS column written by this lane after the reductions: rows of reduce4 hold terms {v0, v2, v1, v3}
     const int row = l >> 4;
@@ -247,10 +258,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                     const float2 r = s_q3[j];
                     const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
                     hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0, bx0 + 7.0f, by0, by1);
-                    hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0 + 8.0f, bx1, by0, by1);
+                    if (!QUAD) hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0 + 8.0f, bx1, by0, by1);
                 }
             }
-            const uint64_t maskL = __ballot(hitL), maskR = __ballot(hitR);
+            const uint64_t maskL = __ballot(hitL), maskR = QUAD ? 0ull : __ballot(hitR);
             uint64_t mask = maskL | maskR;
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
@@ -263,8 +274,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-                if ((maskL >> k) & 1ull) bwd_pixel(PA, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
-                if ((maskR >> k) & 1ull) bwd_pixel(PB, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel(PA, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel(PB, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
@@ -301,6 +312,18 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 
 }  // namespace
 
+bool blend_quad(int num_tiles)
+{
+    static const int forced = [] { const char* e = getenv("LR_BLEND_QUAD_BWD"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    // The backward blend pays its cross-lane reduction per wave and candidate, so the 2-wave shape (a wave owns two
+    // quadrants and reduces once for both) wins once 2 waves per tile come near filling the 1024 SIMDs x 7 wave slots;
+    // below that every workgroup is resident at once, the kernel time is the longest per-wave chain, and the quadrant
+    // shape shortens it (dense 1 M cloud, single view: 256^2 0.22 -> 0.13 ms, 512^2 0.51 -> 0.42, 800^2 0.58 -> 0.53,
+    // 1024^2 equal, 1280x720 0.42 -> 0.44)
+    return num_tiles <= 3072;
+}
+
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
@@ -309,8 +332,12 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int grid = ((num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_bwd, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
-                       final_T, n_contrib, dL_dpix, bin_base, hdr);
+    if (blend_quad(num_tiles))
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
+                           final_T, n_contrib, dL_dpix, bin_base, hdr);
+    else
+        hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(128), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
+                           final_T, n_contrib, dL_dpix, bin_base, hdr);
 }
 
 }  // namespace lr
