@@ -180,12 +180,15 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    host_issue = [0.0]
+
     def timed(n_steps):
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n_steps):
             step()
+        host_issue[0] = (time.perf_counter() - t0) / n_steps * 1e3      # host time to ISSUE a step (no device sync yet)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
@@ -198,6 +201,7 @@ def main():
     for _ in range(args.warmup):
         step()
     dt = timed(args.steps)
+    host_issue_ms = host_issue[0]
     config.drain()
     if batch is not None:
         batch.check()
@@ -275,7 +279,8 @@ def main():
                        "num_rendered_mean": round(R_mean, 1), "sh_degree": degree, "resolution": [W, H],
                        "mode": "exact (host sync per view)" if args.exact else "async (no host sync per view)",
                        "parallelism": f"dp{world} (views sharded, one flat grad all-reduce/step)", "streams_per_rank": args.streams, "api": args.api,
-                       "grad_bucket_bytes": int(grads.flat.numel() * 4)},
+                       "grad_bucket_bytes": int(grads.flat.numel() * 4),
+                       "host_issue_ms_per_step": round(host_issue_ms, 3)},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

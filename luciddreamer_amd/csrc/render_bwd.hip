@@ -58,28 +58,30 @@ __device__ __forceinline__ float row_sum(float v)
     v += dpp<0x140>(v);
     return v;
 }
-// x <- (lanes 0-31: x[l] + x[l+32]) | (lanes 32-63: y[l-32] + y[l]): one swap + one add halves two terms
-// (inline asm: with ROCm 7.2 hipcc, __builtin_amdgcn_permlane32_swap followed by r[0] + r[1] returned
-//  2 * r[0] -- verified on hardware; "s_nop 1" covers the VALU-write -> v_permlane read hazard)
-__device__ __forceinline__ float fold32(float x, float y)
+// (inline asm below: with ROCm 7.2 hipcc, __builtin_amdgcn_permlane32_swap followed by r[0] + r[1] returned 2 * r[0] --
+//  verified on hardware)
+// Reduce eight per-lane terms over the wave down to 16-lane rows: on return row r of `a0` holds the row partials of term
+// {a0, a2, a1, a3}[r] and row r of `b0` those of {b0, b2, b1, b3}[r]; a row_sum of each finishes the job.  One asm block so
+// that the six swaps share two hazard waits instead of paying one each (VALU write -> v_permlane*_swap read needs two
+// wait states, swap -> VALU read one; every dependent pair below has that many instructions in between):
+//   4 x [x <- (lanes<32: x[l] + x[l+32]) | (lanes>=32: y[l-32] + y[l])]   then   2 x the same over 16-lane rows
+__device__ __forceinline__ void reduce8(float& a0, float a1, float a2, float a3, float& b0, float b1, float b2, float b3)
 {
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-// rows: [x0+x1, y0+y1, x2+x3, y2+y3]
-__device__ __forceinline__ float fold16(float x, float y)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-// Reduce four per-lane terms over the wave.  Result: 16-lane row r holds the total of term ROWMAP[r],
-// ROWMAP = {v0, v2, v1, v3}.
-__device__ __forceinline__ float reduce4(float v0, float v1, float v2, float v3)
-{
-    const float s01 = fold32(v0, v1);        // lanes<32: v0 partials, lanes>=32: v1 partials
-    const float s23 = fold32(v2, v3);
-    const float t = fold16(s01, s23);        // rows: v0, v2, v1, v3
-    return row_sum(t);
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %1\n\t"
+                 "v_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\t"
+                 "v_permlane32_swap_b32 %6, %7\n\t"
+                 "v_add_f32 %0, %0, %1\n\t"
+                 "v_add_f32 %2, %2, %3\n\t"
+                 "v_add_f32 %4, %4, %5\n\t"
+                 "v_add_f32 %6, %6, %7\n\t"
+                 "v_permlane16_swap_b32 %0, %2\n\t"
+                 "s_nop 0\n\t"
+                 "v_permlane16_swap_b32 %4, %6\n\t"
+                 "v_add_f32 %0, %0, %2\n\t"
+                 "v_add_f32 %4, %4, %6"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -97,7 +99,7 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
 typedef float v2f __attribute__((ext_vector_type(2)));
 
 // s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
-// 8 db; the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
+// 8-11 db (one column per 16-lane row); the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
 //
 // 128 threads = 2 wave64 per 16x16 tile; a wave owns a 16x8 half tile, a lane owns TWO pixels (same row, 8 columns
 // apart: pixel A in the left 8x8 quadrant of the wave's box, pixel B in the right one).  Per-pixel state lives in
@@ -122,10 +124,17 @@ struct BwdPix {
 // the list), so ONE scalar A replaces three accumulators, and the background term -T_final/(1-alpha) * bg.dL
 // (backward.cu:556-560) is the last layer of the same recursion (A starts at bg.dL); of the geometric gradients only the
 // moments of D = G * dL/dalpha (D, D dx, D dx^2 here; the dy factors and opacity, conic, -0.5, NDC scale later).
+// FIRST: the lane sums are ASSIGNED (first pixel of the lane for this candidate) instead of accumulated -- `0 + a * b` is
+// not foldable under IEEE rules and would cost an extra v_fma per term next to the product that is needed anyway.
+template <bool FIRST>
 __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float Bd, const float Cdd, const float gx,
                                           const float op, const float cr, const float cg, const float cb, const uint32_t pos,
                                           float& sD, float& sMx, float& sMxx, float& sR, float& sG, float& sB)
 {
+    // fold the previous (deeper) layer into A first: it needs only the carried state, and doing it before this layer's
+    // alpha and colour exist lets them be written straight into the state registers (no register-to-register moves)
+    p.A = p.A + p.last_alpha * (p.lcdl - p.A);                             // = last_alpha * lcdl + (1 - last_alpha) * A
+    asm volatile("" : "+v"(p.A));
     const float dx = gx - p.pxf;
     const float power = gauss_power1(Ap, Bd, Cdd, dx);
     const float Graw = __expf(power);
@@ -138,13 +147,17 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     p.T = p.T * rinv;
     const float dchan = alpha * p.T;
     const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;                // colour of this Gaussian . dL/dpixel
-    p.A = p.A + p.last_alpha * (p.lcdl - p.A);                             // = last_alpha * lcdl + (1 - last_alpha) * A
     p.lcdl = cdl;
     p.last_alpha = alpha;
     const float dop = G * ((cdl - p.A) * p.T);                             // G * dL/dalpha
     const float mx = dop * dx;
-    sD += dop; sMx += mx; sMxx += mx * dx;
-    sR += dchan * p.dLr; sG += dchan * p.dLg; sB += dchan * p.dLb;
+    if (FIRST) {
+        sD = dop; sMx = mx; sMxx = mx * dx;
+        sR = dchan * p.dLr; sG = dchan * p.dLg; sB = dchan * p.dLb;
+    } else {
+        sD += dop; sMx += mx; sMxx += mx * dx;
+        sR += dchan * p.dLr; sG += dchan * p.dLg; sB += dchan * p.dLb;
+    }
 }
 
 // 7 waves per SIMD (<= 72 VGPRs)
@@ -158,11 +171,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 {
     constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
-    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, qmax (cull threshold), opacity, -
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, qmax (cull threshold), -   (Cp, opacity: one ds_read_b64)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
-    __shared__ float s_acc[BATCH][9];   // per-batch gradient accumulator (both waves add into it)
+    __shared__ float s_acc[BATCH][12];  // per-batch gradient accumulator (all waves add into it); columns below
     constexpr int NWAVES = QUAD ? 4 : 2;
     __shared__ uint32_t s_wlast[NWAVES];
 
@@ -209,13 +222,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 #pragma unroll
     for (int i = 0; i < NWAVES; i++) tile_last = max(tile_last, s_wlast[i]);
 
-    // LDS column written by this lane after the reductions: rows of reduce4 hold terms {v0, v2, v1, v3}
+    // LDS column written by this lane after the reductions: rows of reduce8 hold terms {v0, v2, v1, v3}
     const int row = l >> 4;
-    const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // reduce4(dmx, dmy, dca, dcb)
-    const int col_b = (row == 0) ? 4 : (row == 1) ? 6 : (row == 2) ? 5 : 7;     // reduce4(dcc, dop, dr, dg)
+    const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // reduce8 a: (dmx, dmy, dca, dcb)
+                                                                                // reduce8 b: (dcc, dop, dr, dg) at col_a + 4
     const bool row_leader = (l & 15) == 0;
-    int opaque_zero = 0;                         // keeps the compiler's uniform-address atomic rewrite away from
-    asm volatile("" : "+v"(opaque_zero));        // the 4-lane LDS add below (it would expand to a readlane loop)
 
     for (int base = 0; base < total; base += BATCH) {
         // staged element i <-> list position pos = total-1-base-i (back to front)
@@ -236,13 +247,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
-            s_q1[tid] = make_float4(-0.5f * b.x, c.z, b.y, 0.f);
+            s_q1[tid] = make_float4(-0.5f * b.x, b.y, c.z, 0.f);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
         }
 #pragma unroll
-        for (int k = 0; k < 9; k++) if (tid < BATCH) s_acc[tid][k] = 0.f;
+        for (int k = 0; k < 12; k++) if (tid < BATCH) s_acc[tid][k] = 0.f;
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
@@ -257,8 +268,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
                     const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
-                    hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0, bx0 + 7.0f, by0, by1);
-                    if (!QUAD) hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0 + 8.0f, bx1, by0, by1);
+                    hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0, bx0 + 7.0f, by0, by1);
+                    if (!QUAD) hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0 + 8.0f, bx1, by0, by1);
                 }
             }
             const uint64_t maskL = __ballot(hitL), maskR = QUAD ? 0ull : __ballot(hitR);
@@ -269,27 +280,29 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const int j = sb + k;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 const float4 a = s_q0[j];
-                const float4 b = s_q1[j];
+                const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);      // Cp, opacity
                 const float4 c = s_q2[j];
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel(PA, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
-                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel(PB, a.z, Bd, Cdd, a.x, b.z, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
-                float ra = reduce4(sMx, sMy, sMxx, sMxy);
-                float rb = reduce4(sMyy, sD, sR, sG);
+                float ra = sMx, rb = sMyy;
+                reduce8(ra, sMy, sMxx, sMxy, rb, sD, sR, sG);
+                ra = row_sum(ra); rb = row_sum(rb);
                 float rc = row_sum(sB);                           // every row: its partial of db
                 // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
                 // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
                 asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
-                float* dst = s_acc[j];
+                // one address per lane: columns col_a, col_a + 4, col_a + 8 (the db partial of each row has its own column)
+                float* dst = s_acc[j] + col_a;
                 if (row_leader) {
-                    atomicAdd(dst + col_a, ra);
-                    atomicAdd(dst + col_b, rb);
-                    atomicAdd(dst + 8 + opaque_zero, rc);
+                    atomicAdd(dst, ra);
+                    atomicAdd(dst + 4, rb);
+                    atomicAdd(dst + 8, rc);
                 }
             }
         }
@@ -300,12 +313,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             // are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of backward.cu:473-474) go in here.
             const float* a9 = s_acc[tid];              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db
             const float4 q0 = s_q0[tid], q1 = s_q1[tid];
-            const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.z;
+            const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
+            const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.y;
             const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
             slot[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
-            slot[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
+            slot[2] = make_float4(db, 0.f, 0.f, 0.f);
         }
     }
 }
