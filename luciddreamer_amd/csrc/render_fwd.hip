@@ -40,26 +40,38 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
     return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 }
 
-// Per-pixel state of the blend
-struct PixState { float T, Cr, Cg, Cb, D, acc; uint32_t last; bool done; };
+// Per-pixel state of the blend.  `last` is what the backward needs from the reference's n_contrib (forward.cu:349, 379:
+// the 1-based list position of the last blended Gaussian): every list position below it is evaluated, everything from it
+// on is skipped.  Here it is the 0-based position of the Gaussian that STOPPED the pixel (T would fall below 1e-4), or
+// the list length for a pixel that never stopped.  The positions between the reference's value and this one hold only
+// Gaussians this pixel skipped (alpha < 1/255 or power > 0), which the backward skips again by the same test on the same
+// arithmetic, so the gradients are identical -- and the common step loses the two instructions that tracked it.
+struct PixState { float T, Cr, Cg, Cb, D, acc; uint32_t last; };
 
-__device__ __forceinline__ void fwd_pixel(PixState& p, const float Ap, const float Bd, const float Cdd, const float dx,
-                                          const float op, const float cr, const float cg, const float cb, const float depth,
-                                          const uint32_t pos1)
+// One candidate for the 64 pixels of the wave.  The per-pixel predicates live in wave-uniform 64-bit lane masks
+// (v_cmp writes them to an SGPR pair; they are combined on the scalar unit and fed back to v_cndmask through
+// inverse_ballot at no VALU cost); `done` is the mask of finished pixels.
+__device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const float Ap, const float Bd, const float Cdd,
+                                          const float dx, const float op, const float cr, const float cg, const float cb,
+                                          const float depth, const uint32_t pos0)
 {
     const float power = gauss_power1(Ap, Bd, Cdd, dx);
     const float alpha = fminf(0.99f, op * __expf(power));
     const float test_T = p.T * (1.0f - alpha);
     // reference order of tests (forward.cu:331-347): power > 0 -> skip; alpha < 1/255 -> skip;
     // T*(1-alpha) < 1e-4 -> pixel done (this Gaussian is NOT blended)
-    const bool pass = !p.done && power <= 0.0f && alpha >= 1.0f / 255.0f;
-    const bool stop = pass && test_T < 0.0001f;
-    const bool use = pass != stop;                                      // stop implies pass
-    p.done = p.done || stop;
+    const uint64_t pass = ~done & __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
+    const uint64_t low_T = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+    const uint64_t stop = pass & low_T;
+    const bool use = __builtin_amdgcn_inverse_ballot_w64(pass & ~low_T);
+    done |= stop;
     const float wgt = use ? alpha * p.T : 0.f;
     p.Cr += cr * wgt; p.Cg += cg * wgt; p.Cb += cb * wgt; p.D += depth * wgt; p.acc += wgt;
     p.T = use ? test_T : p.T;
-    p.last = use ? pos1 : p.last;
+    if (stop != 0ull) {                                                 // rare: a pixel stops at most once
+        asm volatile("");                                               // keep it a scalar branch (no selects in the common path)
+        p.last = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos0 : p.last;
+    }
 }
 
 __global__ void __launch_bounds__(THREADS)
@@ -70,7 +82,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
              float* __restrict__ out_color, float* __restrict__ out_depth)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
-    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, qmax (cull threshold), opacity, depth
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, depth, qmax (cull threshold)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a (edge minimiser slopes for box_hit)
     __shared__ int s_wdone[NWAVES];
@@ -88,8 +100,9 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
-    PixState A = { 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u, !inside };
-    bool wave_done = __ballot(!A.done) == 0;
+    PixState A = { 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u };
+    uint64_t done = __builtin_amdgcn_ballot_w64(!inside);             // lane mask of finished pixels (all 64 lanes are live)
+    bool wave_done = done == ~0ull;
 
     for (int base = 0; base < total; base += BATCH) {
         // all quadrants finished?  (also the barrier that protects the LDS planes of the previous batch)
@@ -102,7 +115,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
-            s_q1[tid] = make_float4(-0.5f * b.x, c.z, b.y, c.y);
+            s_q1[tid] = make_float4(-0.5f * b.x, b.y, c.y, c.z);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
         }
@@ -119,7 +132,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
                     const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
-                    hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.y, bx0, bx1, by0, by1);
+                    hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.w, bx0, bx1, by0, by1);
                 }
             }
             uint64_t mask = __ballot(hit);
@@ -132,12 +145,12 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
                 const float4 a = s_q0[j];
                 const float4 b = s_q1[j];
                 const float4 c = s_q2[j];
-                const uint32_t pos1 = (uint32_t)(base + j + 1);
+                const uint32_t pos0 = (uint32_t)(base + j);
                 const float dy = a.y - pyf;
                 const float Bd = a.w * dy, Cdd = (b.x * dy) * dy;                              // common.h gauss_power
-                fwd_pixel(A, a.z, Bd, Cdd, a.x - pxf, b.z, c.x, c.y, c.z, b.w, pos1);
+                fwd_pixel(A, done, a.z, Bd, Cdd, a.x - pxf, b.y, c.x, c.y, c.z, b.z, pos0);
             }
-            if (__ballot(!A.done) == 0) { wave_done = true; break; }   // all 64 pixels are finished
+            if (done == ~0ull) { wave_done = true; break; }             // all 64 pixels are finished
         }
     }
 
@@ -145,7 +158,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
         const size_t N = (size_t)W * H;
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = A.T;
-        n_contrib[pix] = A.last;
+        n_contrib[pix] = __builtin_amdgcn_inverse_ballot_w64(done) ? A.last : (uint32_t)total;
         out_color[pix] = A.Cr + A.T * bg[0];
         out_color[N + pix] = A.Cg + A.T * bg[1];
         out_color[2 * N + pix] = A.Cb + A.T * bg[2];
