@@ -41,7 +41,9 @@ def init_distributed(backend: Optional[str] = None, device: Optional[torch.devic
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if device.type == "cuda" else "gloo"   # "nccl" IS RCCL on ROCm
+            # "nccl" IS RCCL on ROCm; LR_DIST_BACKEND=gloo lets several ranks share one GPU (debugging on a 1-GPU box:
+            # RCCL refuses two ranks on the same device, gloo stages the all-reduce through the host)
+            backend = os.environ.get("LR_DIST_BACKEND") or ("nccl" if device.type == "cuda" else "gloo")
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = device
