@@ -26,6 +26,7 @@ constexpr int LT = 32;                 // tile edge (outputs)
 constexpr int HALO = 5;                // window 11
 constexpr int LR_IN = LT + 2 * HALO;   // 42
 constexpr int LTHREADS = 256;
+constexpr int NSTAGE = (LR_IN * LR_IN + LTHREADS - 1) / LTHREADS;   // halo elements staged per thread (7)
 
 struct Win { float w[11]; };
 
@@ -64,14 +65,30 @@ k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restr
     const size_t plane = (size_t)ch * H * W;
     const int tid = threadIdx.x;
 
+    // stage the halo region: ALL global loads of the thread are issued before the first LDS store (the workgroup's run
+    // time is a chain of memory round trips at 3-5 waves per SIMD; a rolled loop pays one round trip per iteration)
     float l1_part = 0.f;
-    for (int p = tid; p < LR_IN * LR_IN; p += LTHREADS) {
-        const int ly = p / LR_IN, lx = p % LR_IN;
-        const int y = y0 + ly - HALO, x = x0 + lx - HALO;
-        float a = 0.f, b = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) { a = img[plane + (size_t)y * W + x]; b = gt[plane + (size_t)y * W + x]; }
-        s_i[ly][lx] = a; s_g[ly][lx] = b;
-        if (ly >= HALO && ly < HALO + LT && lx >= HALO && lx < HALO + LT) l1_part += fabsf(a - b);   // outside = 0
+    {
+        float ra[NSTAGE], rb[NSTAGE];
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int p = tid + i * LTHREADS;
+            const int ly = p / LR_IN, lx = p - ly * LR_IN;
+            const int y = y0 + ly - HALO, x = x0 + lx - HALO;
+            const bool ok = p < LR_IN * LR_IN && y >= 0 && y < H && x >= 0 && x < W;
+            const size_t q = ok ? plane + (size_t)y * W + x : 0;
+            const float a = img[q], b = gt[q];
+            ra[i] = ok ? a : 0.f; rb[i] = ok ? b : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int p = tid + i * LTHREADS;
+            const int ly = p / LR_IN, lx = p - ly * LR_IN;
+            if (p < LR_IN * LR_IN) {
+                s_i[ly][lx] = ra[i]; s_g[ly][lx] = rb[i];
+                if (ly >= HALO && ly < HALO + LT && lx >= HALO && lx < HALO + LT) l1_part += fabsf(ra[i] - rb[i]);   // outside = 0
+            }
+        }
     }
     __syncthreads();
 
@@ -169,15 +186,24 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
     const size_t plane = (size_t)ch * H * W;
     const int tid = threadIdx.x;
 
-    for (int p = tid; p < LR_IN * LR_IN; p += LTHREADS) {
-        const int ly = p / LR_IN, lx = p % LR_IN;
-        const int y = y0 + ly - HALO, x = x0 + lx - HALO;
-        float a = 0.f, b = 0.f, c = 0.f;
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            const size_t q = plane + (size_t)y * W + x;
-            a = D1[q]; b = D2[q]; c = D3[q];
+    {
+        float r1[NSTAGE], r2[NSTAGE], r3[NSTAGE];
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {                   // all loads first (see k_ssim_fwd)
+            const int p = tid + i * LTHREADS;
+            const int ly = p / LR_IN, lx = p - ly * LR_IN;
+            const int y = y0 + ly - HALO, x = x0 + lx - HALO;
+            const bool ok = p < LR_IN * LR_IN && y >= 0 && y < H && x >= 0 && x < W;
+            const size_t q = ok ? plane + (size_t)y * W + x : 0;
+            const float a = D1[q], b = D2[q], c = D3[q];
+            r1[i] = ok ? a : 0.f; r2[i] = ok ? b : 0.f; r3[i] = ok ? c : 0.f;
         }
-        s_d[0][ly][lx] = a; s_d[1][ly][lx] = b; s_d[2][ly][lx] = c;
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) {
+            const int p = tid + i * LTHREADS;
+            const int ly = p / LR_IN, lx = p - ly * LR_IN;
+            if (p < LR_IN * LR_IN) { s_d[0][ly][lx] = r1[i]; s_d[1][ly][lx] = r2[i]; s_d[2][ly][lx] = r3[i]; }
+        }
     }
     __syncthreads();
     for (int it = tid; it < LR_IN * (LT / 4); it += LTHREADS) {
