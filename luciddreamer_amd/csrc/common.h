@@ -253,6 +253,8 @@ void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long
 // tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue
 // bound).  LR_BLEND_QUAD_BWD=0/1 forces one (diagnostics).
 bool blend_quad(int num_tiles);
+// hint from the multi-stream view loop (api.hip views_core) to the blend backward launcher: other kernels run beside it
+void set_blend_corun(bool on);
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s);
