@@ -178,18 +178,11 @@ __device__ __forceinline__ float cull_qmax(float opacity)
 }
 
 // ---- launchers (one per translation unit) ------------------------------------------------------
-// Exponent of a splat at two pixels of one row (x offsets dx, common y offset dy):
+// Exponent of a splat at a pixel (offsets dx, dy from the centre):
 //   power = -0.5 (a dx^2 + c dy^2) - b dx dy  (forward.cu:332-334)  =  (Ap dx + Bp dy) dx + Cp dy dy
-// with Ap = -0.5 a, Bp = -b, Cp = -0.5 c formed once per Gaussian when it is staged.  ONE definition shared by the
-// blend forward and backward, so both kernels evaluate alpha with the same operations.
-typedef float lr_v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ lr_v2f gauss_power(float Ap, float Bp, float Cp, lr_v2f dx, float dy)
-{
-    const float Bd = Bp * dy;
-    const float Cdd = (Cp * dy) * dy;
-    return (Ap * dx + Bd) * dx + Cdd;
-}
-// the same expression for ONE pixel
+// with Ap = -0.5 a, Bp = -b, Cp = -0.5 c formed once per Gaussian when it is staged, and Bd = Bp dy, Cdd = (Cp dy) dy
+// formed once per candidate and lane (two pixels of a lane share their row).  ONE definition shared by the blend forward
+// and backward, so both kernels evaluate alpha with the same operations.
 __device__ __forceinline__ float gauss_power1(float Ap, float Bd, float Cdd, float dx)
 {
     return (Ap * dx + Bd) * dx + Cdd;

@@ -38,17 +38,6 @@ __device__ __forceinline__ float dpp(float v)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
 }
-// Sum over the 64 lanes; the total is valid in lanes 48..63.
-__device__ __forceinline__ float wave_sum_hi(float v)
-{
-    v += dpp<0xB1>(v);            // quad_perm [1,0,3,2]
-    v += dpp<0x4E>(v);            // quad_perm [2,3,0,1]
-    v += dpp<0x141>(v);           // row_half_mirror
-    v += dpp<0x140>(v);           // row_mirror          -> every lane: sum of its 16-lane row
-    v += dpp<0x142, 0xa>(v);      // row_bcast:15 into rows 1 and 3
-    v += dpp<0x143, 0xc>(v);      // row_bcast:31 into rows 2 and 3
-    return v;
-}
 // sum within each 16-lane row; every lane of the row ends with the row total
 __device__ __forceinline__ float row_sum(float v)
 {
@@ -95,8 +84,6 @@ __device__ __forceinline__ int swizzled_tile(int num_tiles)
     const int per = (num_tiles + 7) >> 3;
     return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 // s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
 // 8-11 db (one column per 16-lane row); the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
