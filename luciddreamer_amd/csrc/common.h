@@ -246,6 +246,25 @@ void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long
 // tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue
 // bound).  LR_BLEND_QUAD_BWD=0/1 forces one (diagnostics).
 bool blend_quad(int num_tiles);
+// Tile -> workgroup map of the blend kernels.  Workgroup b runs on XCD b % 8 (each XCD has its own L2):
+//   TILE_MAP_BANDS : XCD x renders the contiguous tile band [x T/8, (x+1) T/8): Gaussians that straddle neighbouring tiles
+//                    are re-read from the same L2.
+//   TILE_MAP_PLAIN : tile t is workgroup t (XCD t % 8).  When splats crowd one image region the bands are unevenly loaded
+//                    and the busiest XCD sets the kernel time; spreading every neighbourhood over all XCDs balances it.
+// Measured (dense 1 M cloud, single view, blend forward / backward ms): 512^2 0.178/0.408 -> 0.164/0.334, 800^2
+// 0.211/0.512 -> 0.149/0.378, 1280x720 0.177/0.406 -> 0.170/0.384; at 1080p and 1440p the two maps are within 3 % of
+// each other either way (C3: bands 2 % ahead in the backward), so the large images keep the bands.
+enum { TILE_MAP_BANDS = 0, TILE_MAP_PLAIN = 1 };
+int blend_tile_map(int num_tiles);        // the rule (render_bwd.hip); LR_TILE_MAP=0/1 forces one (diagnostics)
+__device__ __forceinline__ int blend_tile(int map, int num_tiles)
+{
+    int t = (int)blockIdx.x;
+    if (map == TILE_MAP_BANDS) {
+        const int per = (num_tiles + 7) >> 3;
+        t = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    }
+    return t < num_tiles ? t : -1;
+}
 // hint from the multi-stream view loop (api.hip views_core) to the blend backward launcher: other kernels run beside it
 void set_blend_corun(bool on);
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,

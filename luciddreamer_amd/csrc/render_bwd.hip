@@ -79,12 +79,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     return v;
 }
 
-__device__ __forceinline__ int swizzled_tile(int num_tiles)
-{
-    const int per = (num_tiles + 7) >> 3;
-    return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-}
-
 // s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
 // 8-11 db (one column per 16-lane row); the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
 //
@@ -150,7 +144,7 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
 // 7 waves per SIMD (<= 72 VGPRs)
 template <bool QUAD>
 __global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(7, 8)))
-k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
+k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -166,8 +160,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     constexpr int NWAVES = QUAD ? 4 : 2;
     __shared__ uint32_t s_wlast[NWAVES];
 
-    const int tile = swizzled_tile(num_tiles);
-    if (tile >= num_tiles) return;
+    const int tile = blend_tile(tile_map, num_tiles);
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // this wave's box: 16x8 (pixel A left, pixel B right quadrant), or with QUAD the 8x8 quadrant (w&1, w>>1), pixel A only
@@ -313,6 +307,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
 
 }  // namespace
 
+int blend_tile_map(int num_tiles)
+{
+    static const int forced = [] { const char* e = getenv("LR_TILE_MAP"); return e ? atoi(e) : -1; }();
+    if (forced >= 0) return forced;
+    return num_tiles <= 4096 ? TILE_MAP_PLAIN : TILE_MAP_BANDS;
+}
+
 static thread_local bool g_blend_corun = false;
 void set_blend_corun(bool on) { g_blend_corun = on; }
 
@@ -335,6 +336,7 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
+    const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
     // Co-run hint (set by the multi-stream view loop): when kernels of other views run beside this one, 8 KB of unused
     // dynamic LDS cap it at 5 waves per SIMD instead of 7.  Alone it is then 11 % slower (0.102 -> 0.114 ms on C3), but
@@ -343,10 +345,10 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     static const int forced_pad = [] { const char* e = getenv("LR_BWD_LDS_PAD"); return e ? atoi(e) : -1; }();
     const int pad = forced_pad >= 0 ? forced_pad : (g_blend_corun ? 8192 : 0);
     if (blend_quad(num_tiles))
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, bin_base, hdr);
     else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(128), pad, s, W, H, gx, num_tiles, ranges, point_list, rec, bg,
+        hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(128), pad, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, bin_base, hdr);
 }
 

@@ -33,13 +33,6 @@ constexpr int THREADS = 256;        // 4 wave64 per tile
 constexpr int NWAVES = THREADS / 64;
 constexpr int BATCH = 256;          // staged Gaussians per round = threads per workgroup (14 KB of LDS)
 
-__device__ __forceinline__ int swizzled_tile(int num_tiles)
-{
-    // workgroup b lands on XCD (b % 8); give XCD x the contiguous tile band [x*per, (x+1)*per)
-    const int per = (num_tiles + 7) >> 3;
-    return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
-}
-
 // Per-pixel state of the blend.  `last` is what the backward needs from the reference's n_contrib (forward.cu:349, 379:
 // the 1-based list position of the last blended Gaussian): every list position below it is evaluated, everything from it
 // on is skipped.  Here it is the 0-based position of the Gaussian that STOPPED the pixel (T would fall below 1e-4), or
@@ -75,7 +68,7 @@ __device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const flo
 }
 
 __global__ void __launch_bounds__(THREADS)
-k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ ranges,
+k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
              const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -87,8 +80,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, const uint2* __restrict__ rang
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a (edge minimiser slopes for box_hit)
     __shared__ int s_wdone[NWAVES];
 
-    const int tile = swizzled_tile(num_tiles);
-    if (tile >= num_tiles) return;
+    const int tile = blend_tile(tile_map, num_tiles);
+    if (tile < 0) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int x0 = tx * TILE_X + (w & 1) * 8, y0 = ty * TILE_Y + (w >> 1) * 8;      // this wave's 8x8 quadrant
@@ -174,8 +167,9 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
+    const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, ranges, point_list, inst_gid,
+    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid,
                        rec, bg, final_T, n_contrib, out_color, out_depth);
 }
 
