@@ -504,7 +504,7 @@ void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* o
 void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long n_bound, int num_tiles,
                    uint2* ranges, hipStream_t s)
 {
-    hipMemsetAsync(ranges, 0, (size_t)num_tiles * sizeof(uint2), s);
+    (void)hipMemsetAsync(ranges, 0, (size_t)num_tiles * sizeof(uint2), s);    // errors surface at the caller's hipGetLastError
     if (n_bound <= 0) return;
     hipLaunchKernelGGL(k_ranges, dim3((unsigned)((n_bound + 255) / 256)), dim3(256), 0, s, sorted_keys, hdr, ranges);
 }

@@ -141,9 +141,9 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     }
 }
 
-// 7 waves per SIMD (<= 72 VGPRs)
+// 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 27 KB of LDS per workgroup allow 5
 template <bool QUAD>
-__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(7, 8)))
+__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 5 : 7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
