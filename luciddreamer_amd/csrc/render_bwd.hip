@@ -7,14 +7,15 @@
 //
 //   * same two-level loop as the forward: per 64 staged Gaussians one lane each runs the exact
 //     quadrant test (box_hit) -> 64-bit candidate mask; only candidates (walked back to front with
-//     s_flbit) are evaluated per pixel.  Positions at or behind the wave's deepest last contributor
-//     are masked out up front (backward.cu:500-502, made wave-uniform).
+//     s_flbit) are evaluated per pixel.  Positions at or behind the deepest stop position of the wave's pixels
+//     (render_fwd.hip PixState::last) are masked out up front (backward.cu:500-502, made wave-uniform).
 //   * the nine per-(pixel,Gaussian) gradient terms reach memory as
 //       reference: 9 global float atomicAdd per contributing pixel x Gaussian pair (:537-583)
 //       here:      wave64 reduction of 8 terms with v_permlane32_swap / v_permlane16_swap (each swap+add
-//                  halves TWO terms at once) + 4 DPP steps inside the 16-lane rows = 20 instructions
-//                  (a per-term DPP tree costs 48 + hazards nops), 9th term by DPP;
-//                  -> 3 LDS float-add instructions per wave (4+4+1 lanes) into a per-batch accumulator
+//                  halves TWO terms at once, all six swaps in one asm block) + 4 DPP steps inside the 16-lane
+//                  rows = 20 instructions (a per-term DPP tree costs 48 + hazard nops), 9th term by DPP;
+//                  -> 3 LDS float-add instructions per wave (4 lanes each, one address register) into a per-batch
+//                     accumulator
 //                  -> ONE plain 48-byte store per tile instance into that instance's own slot
 //                     (inst_grad[emission index]); the slots of a Gaussian are contiguous and are summed,
 //                     in a fixed order, by k_gauss_bwd.  No global atomics at all, nothing to pre-zero.
@@ -28,10 +29,10 @@ namespace {
 #ifndef LR_QBATCH_BWD
 #define LR_QBATCH_BWD 256           // staging round of the QUAD shape: one Gaussian per thread
 #endif
-constexpr int BATCH2 = 64;          // staged Gaussians per round (64: 8 KB of LDS per workgroup, so registers -- 6 waves per
-                                    // SIMD -- and not LDS limit the occupancy; measured 3 % faster than 128, 32 is slower)
-                                    // threads per workgroup: 128 (2 wave64), or 256 with QUAD (one 8x8 quadrant per wave,
-                                    // one pixel per lane, as in the forward; chosen for small images by blend_quad below)
+constexpr int BATCH2 = 64;          // staged Gaussians per round of the 2-wave shape (7 KB of LDS per workgroup, so registers --
+                                    // 7 waves per SIMD -- and not LDS limit the occupancy; 3 % faster than 128, 32 is slower)
+// threads per workgroup: 128 (2 wave64), or 256 with QUAD (one 8x8 quadrant per wave, one pixel per lane, as in the
+// forward; chosen for small images by blend_quad below)
 
 template <int CTRL, int ROW_MASK = 0xf>
 __device__ __forceinline__ float dpp(float v)
@@ -97,7 +98,7 @@ struct BwdPix {
     float lcdl;         // ... and its colour . dL/dpixel
     float dLr, dLg, dLb;
     float pxf;
-    uint32_t last;      // index of the pixel's last contributor (n_contrib)
+    uint32_t last;      // list positions below this one were blended by the forward (render_fwd.hip PixState::last)
 };
 
 // One layer for one pixel; adds the pixel's terms to the lane sums.  Only what varies per pixel is formed here: the
