@@ -2,8 +2,12 @@
 
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg -- never by the product packages (luciddreamer_amd/,
-depth_diff_gaussian_rasterization_min/, simple_knn/).  PARITY UNPINNED except for the SH
-and cov3D sub-steps (see raster_oracle.c header and tests/golden/).
+depth_diff_gaussian_rasterization_min/, simple_knn/).  Parity of the restatement is pinned by
+tests/test_oracle_ref.py against oracle/_ref (the reference's own .cu sources compiled for the
+host, oracle/build_ref.py) and against the fixtures under tests/golden/.
+
+Two backends share this front-end: "port" = liboracle.so (the restatement, default) and
+"ref" = oracle/_ref/libref_raster.so (see oracle/ref.py); both export the same C signatures.
 
 The argument lists mirror the reference's CudaRasterizer::Rasterizer::{forward,backward,
 markVisible} (RAST/cuda_rasterizer/rasterizer.h:24-86) with numpy float32 arrays.
@@ -29,33 +33,47 @@ def build(force=False):
     return _LIB_PATH
 
 
+STATE_ARRAYS = ("depths", "clamped", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched",
+                "point_list", "point_list_keys", "ranges", "final_T", "n_contrib")
+
+
+class Backend:
+    """One shared library exporting <prefix>forward / backward / mark_visible / dist2 / state_* accessors."""
+
+    def __init__(self, path, prefix, has_fragile):
+        L = ctypes.CDLL(path)
+        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+        self.prefix, self.has_fragile, self.L = prefix, has_fragile, L
+
+        def sym(name, restype, argtypes):
+            f = getattr(L, prefix + name)
+            f.restype, f.argtypes = restype, argtypes
+            setattr(self, name, f)
+        sym("forward", ci, [ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
+                            cf, cf, ci, vp, vp, vp, ctypes.POINTER(vp)])
+        sym("backward", None, [vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
+                               cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp])
+        sym("mark_visible", None, [ci, vp, vp, vp, vp])
+        sym("state_free", None, [vp])
+        sym("state_R", ci, [vp])
+        for name in STATE_ARRAYS + (("fragile",) if has_fragile else ()):
+            sym("state_" + name, vp, [vp])
+        sym("dist2", None, [ci, vp, vp])
+
+
 def lib():
+    """The restatement ("port") backend."""
     global _lib
     if _lib is None:
         build()
-        L = ctypes.CDLL(_LIB_PATH)
-        vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-        L.oracle_forward.restype = ci
-        L.oracle_forward.argtypes = [ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
-                                     cf, cf, ci, vp, vp, vp, ctypes.POINTER(vp)]
-        L.oracle_backward.restype = None
-        L.oracle_backward.argtypes = [vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp,
-                                      cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-        L.oracle_mark_visible.restype = None
-        L.oracle_mark_visible.argtypes = [ci, vp, vp, vp, vp]
-        L.oracle_state_free.restype = None
-        L.oracle_state_free.argtypes = [vp]
-        L.oracle_state_R.restype = ci
-        L.oracle_state_R.argtypes = [vp]
-        for name in ("depths", "clamped", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched",
-                     "point_list", "point_list_keys", "ranges", "final_T", "n_contrib", "fragile"):
-            f = getattr(L, "oracle_state_" + name)
-            f.restype = vp
-            f.argtypes = [vp]
-        L.oracle_dist2.restype = None
-        L.oracle_dist2.argtypes = [ci, vp, vp]
-        _lib = L
+        _lib = Backend(_LIB_PATH, "oracle_", True)
     return _lib
+
+
+def set_accum_f32(on):
+    """True: the backward sums its per-pixel terms in float32 in the order of a one-block-at-a-time run of the
+    reference (bit-comparable with oracle/_ref on one thread); False (default): double accumulators."""
+    lib().L.oracle_set_accum_f32(int(bool(on)))
 
 
 def _f32(a):
@@ -72,19 +90,20 @@ def _ptr(a):
 class ForwardResult:
     """Outputs + the opaque state the backward needs (freed on garbage collection)."""
 
-    def __init__(self):
+    def __init__(self, backend):
         self._state = None
+        self._backend = backend
 
     def __del__(self):
         st, self._state = getattr(self, "_state", None), None
         if st and _lib is not None:          # _lib is None again during interpreter shutdown
             try:
-                _lib.oracle_state_free(st)
+                self._backend.state_free(st)
             except Exception:
                 pass
 
     def _arr(self, name, dtype, count):
-        p = getattr(lib(), "oracle_state_" + name)(self._state)
+        p = getattr(self._backend, "state_" + name)(self._state)
         if count == 0:
             return np.zeros((0,), dtype=dtype)
         buf = (ctypes.c_char * (count * np.dtype(dtype).itemsize)).from_address(p)
@@ -107,15 +126,16 @@ class ForwardResult:
             ranges=self._arr("ranges", np.uint32, 2 * T).reshape(T, 2),
             final_T=self._arr("final_T", np.float32, N).reshape(self.H, self.W),
             n_contrib=self._arr("n_contrib", np.uint32, N).reshape(self.H, self.W),
-            fragile=self._arr("fragile", np.uint8, N).reshape(self.H, self.W),
+            fragile=(self._arr("fragile", np.uint8, N) if self._backend.has_fragile
+                     else np.zeros(N, np.uint8)).reshape(self.H, self.W),
         )
 
 
 def forward(background, means3D, colors_precomp, opacities, scales, rotations, scale_modifier,
             cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width,
-            sh, degree, campos, prefiltered=False):
+            sh, degree, campos, prefiltered=False, backend=None):
     """Same argument order as _C.rasterize_gaussians (RAST/rasterize_points.h:18-38), numpy in/out."""
-    L = lib()
+    L = backend or lib()
     means3D = _f32(means3D)
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise ValueError("means3D must have dimensions (num_points, 3)")
@@ -130,12 +150,12 @@ def forward(background, means3D, colors_precomp, opacities, scales, rotations, s
     out_color = np.zeros((3, H, W), np.float32)
     out_depth = np.zeros((1, H, W), np.float32)
     radii = np.zeros((P,), np.int32)
-    res = ForwardResult()
+    res = ForwardResult(L)
     res.P, res.W, res.H = P, W, H
     res.num_rendered = 0
     if P != 0:
         st = ctypes.c_void_p()
-        R = L.oracle_forward(P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(shs), _ptr(col),
+        R = L.forward(P, int(degree), M, _ptr(bg), W, H, _ptr(means3D), _ptr(shs), _ptr(col),
                              _ptr(op), _ptr(sc), float(scale_modifier), _ptr(rot), _ptr(cov),
                              _ptr(view), _ptr(proj), _ptr(cam), float(tan_fovx), float(tan_fovy),
                              int(bool(prefiltered)), _ptr(out_color), _ptr(out_depth), _ptr(radii),
@@ -156,7 +176,7 @@ def backward(res, dL_dout_color, dL_dout_depth=None):
     """Returns the reference's 8-tuple order (RAST/rasterize_points.cu:199):
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     plus dL_dconic as a 9th element for stage tests."""
-    L = lib()
+    L = res._backend
     i = res._inputs
     P, H, W, M = res.P, res.H, res.W, i["M"]
     g = _f32(dL_dout_color)
@@ -171,7 +191,7 @@ def backward(res, dL_dout_color, dL_dout_depth=None):
     dscales = np.zeros((P, 3), np.float32)
     drot = np.zeros((P, 4), np.float32)
     if P != 0:
-        L.oracle_backward(res._state, P, i["degree"], M, _ptr(i["bg"]), W, H, _ptr(i["means3D"]),
+        L.backward(res._state, P, i["degree"], M, _ptr(i["bg"]), W, H, _ptr(i["means3D"]),
                           _ptr(i["shs"]), _ptr(i["col"]), _ptr(i["sc"]), i["scale_modifier"], _ptr(i["rot"]),
                           _ptr(i["cov"]), _ptr(i["view"]), _ptr(i["proj"]), _ptr(i["cam"]),
                           i["tan_fovx"], i["tan_fovy"], _ptr(g), _ptr(gd),
@@ -180,20 +200,20 @@ def backward(res, dL_dout_color, dL_dout_depth=None):
     return dmeans2D, dcolors, dopacity, dmeans3D, dcov3D, dsh, dscales, drot, dconic
 
 
-def mark_visible(means3D, viewmatrix, projmatrix):
+def mark_visible(means3D, viewmatrix, projmatrix, backend=None):
     means3D = _f32(means3D)
     P = means3D.shape[0]
     out = np.zeros((P,), np.uint8)
     if P:
-        lib().oracle_mark_visible(P, _ptr(means3D), _ptr(_f32(viewmatrix)), _ptr(_f32(projmatrix)), _ptr(out))
+        (backend or lib()).mark_visible(P, _ptr(means3D), _ptr(_f32(viewmatrix)), _ptr(_f32(projmatrix)), _ptr(out))
     return out.astype(bool)
 
 
-def dist2(points):
+def dist2(points, backend=None):
     """simple_knn distCUDA2 contract (KNN/spatial.cu:15-26)."""
     pts = _f32(points)
     P = pts.shape[0]
     out = np.zeros((P,), np.float32)
     if P:
-        lib().oracle_dist2(P, _ptr(pts), _ptr(out))
+        (backend or lib()).dist2(P, _ptr(pts), _ptr(out))
     return out
