@@ -8,9 +8,9 @@ Plain-torch restatement, on whatever device the tensors live on (tests use the C
 and R/utils/general.py:78-100 build_rotation.  The "model" is a dict:
     params: {xyz,f_dc,f_rest,opacity,scaling,rotation}, exp_avg / exp_avg_sq: same keys (Adam moments),
     xyz_gradient_accum [P,1], denom [P,1], max_radii2D [P], percent_dense.
-PARITY UNPINNED: the reference's GaussianModel hard-codes device="cuda" and imports plyfile and simple_knn, none of
-which exist in the build container, so these functions could not be executed against it; they follow its source
-line by line with boolean-mask indexing and torch.cat, exactly the operations the reference uses.
+Pinned by tests/test_densify_oracle_ref.py: the reference's GaussianModel is imported unchanged and run on CPU tensors
+(oracle/ref_python.py maps its hard-coded device="cuda" to the CPU and stands in for plyfile / simple_knn); parameters,
+both Adam moments and the statistics tensors agree bit for bit after prune / clone / split / densify_and_prune.
 """
 import torch
 

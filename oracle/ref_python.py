@@ -148,7 +148,9 @@ def reference_modules(rasterizer="ours"):
         raise RuntimeError("neither /root/reference nor oracle/_ref/py is present")
     saved = {k: v for k, v in sys.modules.items() if k.split(".")[0] in _OURS}
     for k in list(saved):
-        if k.split(".")[0] in ("utils", "scene", "gaussian_renderer", "arguments") or rasterizer != "ours":
+        top = k.split(".")[0]
+        if top in ("utils", "scene", "gaussian_renderer", "arguments") or \
+                (rasterizer != "ours" and top in ("depth_diff_gaussian_rasterization_min", "simple_knn")):
             del sys.modules[k]
     try:
         if "plyfile" not in sys.modules:
