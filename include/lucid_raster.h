@@ -80,7 +80,8 @@ size_t lr_binning_bytes(long long R);
  * binning_capacity  > 0  (async mode): no host synchronisation at all.  The binning buffer is
  *     sized for `binning_capacity` tile instances; num_rendered stays in the geom buffer header.
  *     If the view needs more, nothing is written out of bounds, the overflow flag in the header
- *     is set and lr_backward / lr_check return LR_ERR_OVERFLOW.
+ *     is set and lr_check (or lr_views_check for the multi-view entry points) returns LR_ERR_OVERFLOW; lr_backward
+ *     does not look at the flag (it would cost a host synchronisation) and differentiates the truncated image.
  *
  * out_color [3,H,W], out_depth [1,H,W], radii [P] are fully written (no pre-fill needed).
  */
@@ -118,6 +119,8 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
  * accumulate_mask: bit k set (LR_ACC_*) => that output is ACCUMULATED into (rows of visible Gaussians are
  * added to the existing contents, rows of culled Gaussians are not touched); bit clear => the output is
  * fully written (zero rows for culled Gaussians), no pre-fill needed.  0 reproduces the reference contract.
+ * Every gradient output pointer (in either mode) must be 16-byte aligned: the kernels use 16-byte vector
+ * accesses on them; a misaligned pointer is rejected with LR_ERR_INVALID_ARG.
  * Outputs:
  *   dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (slots x,y,w; may be NULL), dL_dopacity [P],
  *   dL_dcolor [P,3], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (NULL iff shs NULL),

@@ -6,9 +6,10 @@ per forward (RAST/cuda_rasterizer/rasterizer_impl.cu:281-282) to size the binnin
 Async mode removes that host round trip so the CPU can enqueue many views ahead of the GPU:
 the binning buffer is sized from the high-water mark of num_rendered seen so far for the same
 (P, H, W) times a headroom factor.  Every async forward leaves its true count and an overflow flag in
-the geom-buffer header; a non-blocking copy of the header is polled on later calls.  If a view ever
-overflowed, the NEXT rasterizer call raises (that earlier image was incomplete) -- callers that cannot
-accept a deferred error keep exact mode.  The first `warm_calls` forwards of every (P, H, W) still run exact, so
+the geom-buffer header; a non-blocking 32-byte copy of the header is taken after every forward (check_every=1, the
+default; a larger value samples every k-th view only and can miss an overflow of the views in between) and polled on
+later calls.  If a checked view overflowed, a later rasterizer call (or config.drain()) raises -- that earlier image
+was incomplete -- so callers that cannot accept a deferred error keep exact mode.  The first `warm_calls` forwards of every (P, H, W) still run exact, so
 that the mark is taken over several views of a camera path rather than the first one only; a training loop whose
 counts keep growing (scales change, densification) can pass on_overflow="warn" to keep going with a raised
 capacity instead of an exception.
@@ -22,7 +23,7 @@ _fused_accumulate = False
 _headroom = 1.3
 _hwm = {}            # (device, P, H, W) -> largest num_rendered observed
 _pending = []        # [(event, pinned_header, key)]
-_CHECK_EVERY = 8      # async mode: every k-th forward gets its header copied back and checked
+_CHECK_EVERY = 1      # async mode: every k-th forward gets its header copied back and checked
 _calls = 0
 _pinned_pool = []
 _warm_calls = 1
@@ -30,10 +31,11 @@ _seen = {}           # key -> forwards seen
 _on_overflow = "raise"
 
 
-def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 8, warm_calls: int = 1,
+def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 1, warm_calls: int = 1,
               on_overflow: str = "raise"):
     """check_every: every k-th async forward has its header (true instance count, overflow flag) copied back
-    without blocking and examined on a later call; 1 checks every view.
+    without blocking and examined on a later call; 1 (default) checks every view, k > 1 only every k-th (views in
+    between can overflow unnoticed and do not feed the high-water mark).
     warm_calls: the first this-many forwards of a (P, H, W) run in exact mode and feed the high-water mark.
     on_overflow: "raise" (default) or "warn" when a deferred overflow is discovered."""
     global _async, _headroom, _CHECK_EVERY, _warm_calls, _on_overflow

@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstddef>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -48,12 +50,16 @@ const char* const kStageNames[ST_COUNT] = { "preprocess", "compact", "depth_sort
                                             "render_fwd", "grad_zero", "render_bwd", "out_zero", "gauss_bwd" };
 struct ProfRec { int stage; hipEvent_t e0, e1; };
 bool g_prof_on = false;
+std::mutex g_prof_mu;                    // the profiler is a single-device diagnostic; the lock only keeps it memory-safe
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 
 hipEvent_t prof_event()
 {
-    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    }
     hipEvent_t e = nullptr;
     (void)hipEventCreate(&e);
     return e;
@@ -66,7 +72,7 @@ struct ProfScope {
     }
     ~ProfScope()
     {
-        if (on) { (void)hipEventRecord(r.e1, s); g_prof_recs.push_back(r); }
+        if (on) { (void)hipEventRecord(r.e1, s); std::lock_guard<std::mutex> lock(g_prof_mu); g_prof_recs.push_back(r); }
     }
 };
 
@@ -307,6 +313,13 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
     if (cov3D_precomp != nullptr && !dL_dcov3D) return fail(LR_ERR_INVALID_ARG, "dL_dcov3D is required with cov3D_precomp");
     if (scales != nullptr && (!dL_dscale || !dL_drot)) return fail(LR_ERR_INVALID_ARG, "dL_dscale/dL_drot are required with scales");
     if (shs != nullptr && dL_dsh == nullptr) return fail(LR_ERR_INVALID_ARG, "dL_dsh is required when shs is given");
+    {   // gradient tensors are read / written with 16-byte vector accesses (write mode and accumulate mode alike)
+        const void* g16[10] = { dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                                raw ? raw->dL_dsh_rest : nullptr };
+        for (const void* p : g16)
+            if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0)
+                return fail(LR_ERR_INVALID_ARG, "gradient outputs must be 16-byte aligned");
+    }
 
     const int gx = (width + TILE_X - 1) / TILE_X, gy = (height + TILE_Y - 1) / TILE_Y;
     const GeomLayout GL = geom_layout(P);
@@ -439,8 +452,13 @@ char* slice_alloc(size_t bytes, void* user)
     SliceCookie* c = static_cast<SliceCookie*>(user);
     return bytes <= c->bytes ? c->ptr : nullptr;
 }
-hipStream_t g_view_streams[kMaxViewStreams] = { nullptr, nullptr, nullptr, nullptr };
-hipEvent_t g_view_events[2 * kMaxViewStreams + 2] = {};
+// internal streams / events of the multi-view entry points: one set per device, created on first use
+struct ViewStreamSet {
+    hipStream_t streams[kMaxViewStreams] = { nullptr, nullptr, nullptr, nullptr };
+    hipEvent_t events[2 * kMaxViewStreams + 2] = {};
+};
+std::mutex g_view_mu;
+std::map<int, ViewStreamSet> g_view_sets;
 }  // namespace
 
 size_t lr_views_workspace_bytes(int P, int width, int height, long long binning_capacity, int n_streams)
@@ -472,20 +490,30 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
     if (!acc_mean2D || !acc_opacity || !acc_mean3D) return fail(LR_ERR_INVALID_ARG, "acc_mean2D/acc_opacity/acc_mean3D are required");
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
+    const int n_slots = n_streams;                 // slots the caller's workspace was sized for (lr_views_check reads all)
     if (n_streams > n_views) n_streams = n_views;
     const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity, with_loss);
     if (workspace_bytes < SL.total * (size_t)n_streams) return fail(LR_ERR_INVALID_ARG, "workspace too small (lr_views_workspace_bytes)");
 
-    for (int i = 0; i < n_streams; i++)
-        if (!g_view_streams[i]) LR_HIP_CHECK(hipStreamCreateWithFlags(&g_view_streams[i], hipStreamNonBlocking));
-    for (int i = 0; i < 2 * kMaxViewStreams + 2; i++)
-        if (!g_view_events[i]) LR_HIP_CHECK(hipEventCreateWithFlags(&g_view_events[i], hipEventDisableTiming));
-    hipEvent_t ev_fork = g_view_events[0];
-    hipEvent_t* ev_bwd = &g_view_events[1];                     // ring of n_streams + 1 "accumulation done" events
-    hipEvent_t* ev_join = &g_view_events[2 + kMaxViewStreams];
+    int device = 0;
+    LR_HIP_CHECK(hipGetDevice(&device));
+    ViewStreamSet* vs;
+    {
+        std::lock_guard<std::mutex> lock(g_view_mu);
+        vs = &g_view_sets[device];                              // std::map: the address stays valid
+        for (int i = 0; i < n_streams; i++)
+            if (!vs->streams[i]) LR_HIP_CHECK(hipStreamCreateWithFlags(&vs->streams[i], hipStreamNonBlocking));
+        for (int i = 0; i < 2 * kMaxViewStreams + 2; i++)
+            if (!vs->events[i]) LR_HIP_CHECK(hipEventCreateWithFlags(&vs->events[i], hipEventDisableTiming));
+    }
+    hipStream_t* const g_view_streams = vs->streams;
+    hipEvent_t ev_fork = vs->events[0];
+    hipEvent_t* ev_bwd = &vs->events[1];                        // ring of n_streams + 1 "accumulation done" events
+    hipEvent_t* ev_join = &vs->events[2 + kMaxViewStreams];
 
-    // sticky per-slot overflow words (see GeomHeader::sticky_overflow) start at zero; fork the streams
-    for (int i = 0; i < n_streams; i++) {
+    // sticky per-slot overflow words (see GeomHeader::sticky_overflow) start at zero -- in EVERY slot of the workspace,
+    // also the ones a step with fewer views than streams leaves unused (lr_views_check reads them all); fork the streams
+    for (int i = 0; i < n_slots && (size_t)(i + 1) * SL.total <= workspace_bytes; i++) {
         GeomHeader* hdr = reinterpret_cast<GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
         LR_HIP_CHECK(hipMemsetAsync(&hdr->sticky_overflow, 0, 4, caller));
     }
@@ -743,6 +771,7 @@ int lr_check(const char* geom_buffer, long long* num_rendered, void* stream_)
 
 int lr_profile_enable(int on)
 {
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
     g_prof_recs.clear();
     g_prof_on = on != 0;
@@ -755,6 +784,7 @@ int lr_profile_read(double* ms_per_stage, long long* calls_per_stage, int n_stag
 {
     if (!ms_per_stage || !calls_per_stage || n_stages < ST_COUNT) return fail(LR_ERR_INVALID_ARG, "need ST_COUNT slots");
     for (int i = 0; i < n_stages; i++) { ms_per_stage[i] = 0.0; calls_per_stage[i] = 0; }
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     for (auto& r : g_prof_recs) {
         LR_HIP_CHECK(hipEventSynchronize(r.e1));
         float ms = 0.f;

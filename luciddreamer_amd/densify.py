@@ -14,9 +14,9 @@ _opacity, _scaling, _rotation, optimizer with named param groups, xyz_gradient_a
 percent_dense).  `patch(GaussianModel)` installs these functions as that class's methods.
 
 How it differs from the reference inside: all row tensors (6 parameters, up to 12 Adam moments, 3 statistics) live in
-capacity-sized ping-pong buffers (RowStore); a prune is ONE order-preserving lr_select_rows call over all of them into
-the other half, an append copies the selected rows behind the live ones, and parameters / Adam moments become views of
-the store (six new nn.Parameter objects per change of size, no data copied for them).
+capacity-sized buffers (RowStore); a prune is ONE order-preserving lr_select_rows call over all of them into a fresh set
+(the old one is released afterwards), an append copies the selected rows behind the live ones, and parameters / Adam
+moments become views of the store (six new nn.Parameter objects per change of size, no data copied for them).
 No per-tensor boolean indexing, no torch.cat, no empty_cache().  The only host
 synchronisation is reading the selected-row count (tensor shapes must be known to PyTorch).
 Requires the HIP library (no CPU path).
@@ -36,7 +36,9 @@ STAT_ATTRS = ("xyz_gradient_accum", "denom", "max_radii2D")
 
 
 class RowStore:
-    """Capacity-managed ping-pong storage for a set of row tensors that always have the same number of rows."""
+    """Capacity-managed storage for a set of row tensors that always have the same number of rows.  One capacity-sized
+    buffer per tensor; a compaction gathers into a freshly allocated set and releases the old one (so two copies
+    exist only for the duration of a prune), an append writes behind the live rows of the same buffers."""
 
     def __init__(self, tensors, capacity=None, growth=1.5):
         self.P = int(next(iter(tensors.values())).shape[0])
@@ -45,29 +47,31 @@ class RowStore:
             raise RuntimeError("luciddreamer_amd.densify needs tensors on a HIP device (no CPU path)")
         self.growth = float(growth)
         self.cap = max(int(capacity or 0), int(self.P * self.growth) + 1024)
-        self.row_shape, self.bufs, self.active = {}, {}, 0
+        self.row_shape, self.bufs = {}, {}
         for name, t in tensors.items():
             self._add(name, t)
         self._ws = None
         self._count = torch.zeros((1,), dtype=torch.int32, device=self.device)
 
+    def _alloc(self, name, cap):
+        return torch.zeros((cap,) + self.row_shape[name], dtype=torch.float32, device=self.device)
+
     def _add(self, name, t):
         if t.dtype != torch.float32 or int(t.shape[0]) != self.P:
             raise RuntimeError(f"RowStore: {name} must be float32 with {self.P} rows")
         self.row_shape[name] = tuple(t.shape[1:])
-        pair = [torch.zeros((self.cap,) + self.row_shape[name], dtype=torch.float32, device=self.device) for _ in range(2)]
-        pair[self.active][:self.P].copy_(t.detach())
-        self.bufs[name] = pair
+        self.bufs[name] = self._alloc(name, self.cap)
+        self.bufs[name][:self.P].copy_(t.detach())
 
     def add_zero(self, name, row_shape):
         self.row_shape[name] = tuple(row_shape)
-        self.bufs[name] = [torch.zeros((self.cap,) + tuple(row_shape), dtype=torch.float32, device=self.device) for _ in range(2)]
+        self.bufs[name] = self._alloc(name, self.cap)
 
     def names(self):
         return list(self.bufs.keys())
 
     def view(self, name, start=0, stop=None):
-        return self.bufs[name][self.active][start:self.P if stop is None else stop]
+        return self.bufs[name][start:self.P if stop is None else stop]
 
     def row_bytes(self, name):
         n = 1
@@ -79,23 +83,26 @@ class RowStore:
         if rows <= self.cap:
             return
         new_cap = max(int(rows * self.growth) + 1024, rows)
-        for name, pair in self.bufs.items():
-            fresh = [torch.zeros((new_cap,) + self.row_shape[name], dtype=torch.float32, device=self.device) for _ in range(2)]
-            fresh[self.active][:self.P].copy_(pair[self.active][:self.P])
+        for name, old in list(self.bufs.items()):
+            fresh = self._alloc(name, new_cap)
+            fresh[:self.P].copy_(old[:self.P])
             self.bufs[name] = fresh
         self.cap = new_cap
 
-    def _select(self, mask_u8, n_rows, names, src_half, dst_half, dst_row_offset):
+    def _select(self, mask_u8, n_rows, names, src, dst, dst_row_offset):
+        """src / dst: {name: buffer}.  Zero-width tensors (e.g. features_rest of a degree-0 model, [P,0,3]) have
+        nothing to move and are left out of the launch."""
         L = _lib.lib()
+        names = [k for k in names if self.row_bytes(k) > 0]
         need = L.lr_select_workspace_bytes(n_rows)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty((need,), dtype=torch.uint8, device=self.device)
         n = len(names)
-        src = (ctypes.c_void_p * max(n, 1))(*[self.bufs[k][src_half].data_ptr() for k in names])
-        dst = (ctypes.c_void_p * max(n, 1))(*[self.bufs[k][dst_half].data_ptr() for k in names])
+        srcp = (ctypes.c_void_p * max(n, 1))(*[src[k].data_ptr() for k in names])
+        dstp = (ctypes.c_void_p * max(n, 1))(*[dst[k].data_ptr() for k in names])
         rb = (ctypes.c_uint * max(n, 1))(*[self.row_bytes(k) for k in names])
         with torch.cuda.device(self.device):
-            rc = L.lr_select_rows(n_rows, mask_u8.data_ptr(), n, src, dst, rb, int(dst_row_offset), self._count.data_ptr(),
+            rc = L.lr_select_rows(n_rows, mask_u8.data_ptr(), n, srcp, dstp, rb, int(dst_row_offset), self._count.data_ptr(),
                                   self._ws.data_ptr(), self._ws.numel(), torch.cuda.current_stream(self.device).cuda_stream)
         if rc < 0:
             _lib.raise_for(rc, "lr_select_rows")
@@ -111,8 +118,9 @@ class RowStore:
     def compact(self, keep_mask):
         """Keep the rows with keep_mask True, in order (all tensors, one call).  Returns the new row count."""
         m = self._mask_u8(keep_mask, self.P)
-        count = self._select(m, self.P, self.names(), self.active, 1 - self.active, 0)
-        self.active = 1 - self.active
+        fresh = {k: self._alloc(k, self.cap) for k in self.names()}
+        count = self._select(m, self.P, self.names(), self.bufs, fresh, 0)
+        self.bufs = fresh                                  # the old set is released once its last view is dropped
         self.P = count
         return count
 
@@ -121,15 +129,15 @@ class RowStore:
         (block-wise, like tensor[mask].repeat(N, ...)).  Tensors not in `names` get zero rows.  Returns (start, count)."""
         n_src = int(mask.numel())
         m = self._mask_u8(mask, n_src)
-        count = self._select(m, n_src, [], self.active, self.active, 0)       # count only
+        count = self._select(m, n_src, [], self.bufs, self.bufs, 0)           # count only
         start = self.P
         self.ensure_capacity(self.P + repeat * count)
         if count:
             for r in range(repeat):
-                self._select(m, n_src, list(names), self.active, self.active, start + r * count)
+                self._select(m, n_src, list(names), self.bufs, self.bufs, start + r * count)
             for k in self.names():
                 if k not in names:
-                    self.bufs[k][self.active][start:start + repeat * count].zero_()
+                    self.bufs[k][start:start + repeat * count].zero_()
         self.P = start + repeat * count
         return start, count
 
@@ -248,7 +256,7 @@ def densification_postfix(model, new_xyz, new_features_dc, new_features_rest, ne
     new = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
            "scaling": new_scaling, "rotation": new_rotation}
     for k in st.names():
-        tail = st.bufs[k][st.active][start:start + n]
+        tail = st.bufs[k][start:start + n]
         if k in new:
             tail.copy_(new[k].detach())
         else:
@@ -304,8 +312,8 @@ def densify_and_split(model, grads, grad_threshold, scene_extent, N=2, samples=N
     # rotation, SH and opacity rows are copied by the row kernel (N blocks); xyz and scaling are overwritten
     start, count = st.append_selected(sel, list(GROUP_ATTR.keys()), repeat=N)
     if count:
-        st.bufs["xyz"][st.active][start:start + N * count].copy_(new_xyz)
-        st.bufs["scaling"][st.active][start:start + N * count].copy_(new_scaling)
+        st.bufs["xyz"][start:start + N * count].copy_(new_xyz)
+        st.bufs["scaling"][start:start + N * count].copy_(new_scaling)
     for a in STAT_ATTRS:
         st.view(a).zero_()
     _bind(model, st)

@@ -13,6 +13,7 @@ from types import SimpleNamespace
 import torch
 
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer, rasterize_gaussians_raw
+from .sh import colors_from_shs
 
 DEFAULT_OPT = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
 
@@ -55,8 +56,9 @@ def render(viewpoint_camera, pc, opt=DEFAULT_OPT, bg_color=None, scaling_modifie
     shs = colors_precomp = None
     if override_color is None:
         if getattr(opt, "convert_SHs_python", False):
-            raise NotImplementedError("convert_SHs_python: evaluate SH in the caller and pass override_color")
-        shs = pc.get_features
+            colors_precomp = colors_from_shs(pc, viewpoint_camera.camera_center)      # :73-78
+        else:
+            shs = pc.get_features
     else:
         colors_precomp = override_color
 

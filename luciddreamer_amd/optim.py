@@ -38,14 +38,16 @@ class FusedAdam(torch.optim.Optimizer):
                     raise RuntimeError("FusedAdam does not support sparse gradients")
                 st = self.state[p]
                 if len(st) == 0:
-                    st["step"] = 0
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)     # a host tensor, as torch.optim.Adam keeps it
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
+                if not torch.is_tensor(st["step"]):                             # state loaded from an older checkpoint
+                    st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+                st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):
                     raise RuntimeError("FusedAdam needs contiguous parameters and moments")
-                key = (group["betas"][0], group["betas"][1], group["eps"], st["step"], p.device)
+                key = (group["betas"][0], group["betas"][1], group["eps"], int(st["step"].item()), p.device)
                 batches.setdefault(key, []).append((p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"])))
         for (b1, b2, eps, step, dev), items in batches.items():
             for i in range(0, len(items), 16):

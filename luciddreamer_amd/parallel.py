@@ -72,18 +72,22 @@ def shard_views(n_views: int, rank: Optional[int] = None, world: Optional[int] =
 class FlatGrads:
     """One contiguous fp32 buffer holding the gradients of all parameters; p.grad are views into it."""
 
+    ALIGN = 4      # floats: every segment starts on a 16-byte boundary (the HIP kernels accumulate with 16-byte accesses)
+
     def __init__(self, params: Sequence[torch.Tensor]):
         self.params = list(params)
-        total = sum(p.numel() for p in self.params)
+        pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        total = sum(pad(p.numel()) for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
-        self.views = []
+        self.views, self.segments = [], []
         for p in self.params:
             v = self.flat[off:off + p.numel()].view_as(p)
             p.grad = v
             self.views.append(v)
-            off += p.numel()
+            self.segments.append((off, p.numel()))
+            off += pad(p.numel())
 
     def zero_(self):
         self.flat.zero_()
@@ -211,6 +215,10 @@ class ViewBatch:
         for t in (means3D, opacities, scales, rotations, shs, *acc.values()):
             if not (t.is_cuda and t.dtype is torch.float32 and t.is_contiguous()):
                 raise RuntimeError("ViewBatch.run needs contiguous float32 tensors on the HIP device")
+        with torch.cuda.device(self.device):
+            self._run(P, M, means3D, opacities, scales, rotations, shs, acc)
+
+    def _run(self, P, M, means3D, opacities, scales, rotations, shs, acc):
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if self.train:
             rc = self.L.lr_views_train_accumulate(
@@ -239,8 +247,9 @@ class ViewBatch:
             return
         P = self._ws_key[0]
         check = self.L.lr_views_train_check if self.train else self.L.lr_views_check
-        rc = check(self._ws.data_ptr(), P, self.W, self.H, self.capacity, self.n_streams,
-                   torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            rc = check(self._ws.data_ptr(), P, self.W, self.H, self.capacity, self.n_streams,
+                       torch.cuda.current_stream(self.device).cuda_stream)
         if rc < 0:
             self._lib.raise_for(rc, "lr_views_check")
 

@@ -81,7 +81,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             accumulate_into = {}
             for name, t in ctx.leaf_inputs.items():
                 g = t.grad if (t.is_leaf and t.requires_grad and t.numel() != 0) else None
-                if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == means3D.device:
+                if g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == means3D.device \
+                        and g.data_ptr() % 16 == 0:      # the kernels accumulate with 16-byte accesses; else: dense path
                     accumulate_into[name] = g
         try:
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
@@ -135,7 +136,8 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         if ctx.leaf_inputs is not None:
             def leaf_grad(t):
                 g = t.grad if (t.is_leaf and t.requires_grad and t.numel() != 0) else None
-                ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == xyz.device
+                ok = g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.device == xyz.device \
+                    and g.data_ptr() % 16 == 0
                 return g if ok else None
             li = ctx.leaf_inputs
             accumulate_into = {k: leaf_grad(li[k]) for k in ("xyz", "means2D", "opacity", "scaling", "rotation")}

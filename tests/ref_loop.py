@@ -33,7 +33,7 @@ def model_from_cloud(R, cloud, device, sh_degree=3, active_sh_degree=None):
 
 
 def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, depth_weight=0.1, densify_from=10 ** 9,
-          densify_every=100, extent=3.0, opt=None, on_iteration=None, seed=0):
+          densify_every=100, extent=3.0, opt=None, on_iteration=None, on_loss=None, seed=0):
     """luciddreamer.py:283-327 with `order[it]` as the camera index.  Returns dict(loss=[...], P=[...])."""
     opt = opt or R.arguments.GSParams()
     opt.iterations = iters + 1                      # the reference skips the optimizer step at the last iteration (:325)
@@ -57,6 +57,8 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
         loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, tg[k]))
         if dg is not None:       # a depth term: enters the loss, contributes no parameter gradient (backward.cu:539-554)
             loss = loss + depth_weight * l1_loss(pkg["depth"], dg[k])
+        if on_loss is not None:
+            on_loss(iteration, gm, pkg, loss, k)
         loss.backward()                                                            # :304
         with torch.no_grad():
             gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], radii[vis])       # :310-312

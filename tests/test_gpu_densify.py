@@ -121,6 +121,25 @@ def test_clone_split_prune_sequence(hip_device):
     assert_same(model, m, exact=False)
 
 
+def test_degree0_model_with_zero_width_features_rest(hip_device):
+    """max_sh_degree = 0: _features_rest is [P, 0, 3] (R/scene/gaussian_model.py:144); prune / clone must work on it."""
+    from luciddreamer_amd import densify as D
+    P = 5000
+    model = Model(P, hip_device, seed=12, n_rest=0)
+    model.max_sh_degree = 0
+    m = to_oracle(model)
+    mask = torch.rand(P, generator=torch.Generator().manual_seed(2)) < 0.4
+    D.prune_points(model, mask.to(hip_device))
+    O.prune_points(m, mask)
+    assert model._features_rest.shape == (int((~mask).sum()), 0, 3)
+    assert_same(model, m)
+    grads = model.xyz_gradient_accum / model.denom
+    grads[grads.isnan()] = 0.0
+    D.densify_and_clone(model, grads, 2e-4, 5.0)
+    O.densify_and_clone(m, grads.cpu().clone(), 2e-4, 5.0)
+    assert_same(model, m)
+
+
 def test_densify_and_prune_end_to_end(hip_device):
     from luciddreamer_amd import densify as D
     P = 30000

@@ -376,6 +376,26 @@ def test_view_batch_equals_autograd_accumulation(hip_device):
         small.check()
 
 
+def test_view_batch_with_fewer_views_than_streams(hip_device):
+    """One view on a 3-stream ViewBatch (8 views over 8 GPUs leave 1 view per rank): the overflow words of the unused
+    slots of a torch.empty workspace must not be read as garbage by check()."""
+    from luciddreamer_amd import parallel
+    cloud = {k: v.to(hip_device) for k, v in synthetic.make_cloud(8_000, "band", 3).items()}
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(128, 96, n_views=1)]
+    g = synthetic.upstream_grad(96, 128).to(hip_device)
+    acc = {"means3D": torch.zeros(8_000, 3, device=hip_device), "means2D": torch.zeros(8_000, 3, device=hip_device),
+           "opacity": torch.zeros(8_000, 1, device=hip_device), "sh": torch.zeros(8_000, 16, 3, device=hip_device),
+           "scales": torch.zeros(8_000, 3, device=hip_device), "rotations": torch.zeros(8_000, 4, device=hip_device)}
+    batch = parallel.ViewBatch(cams, [g], 3, torch.zeros(3, device=hip_device), binning_capacity=100_000, n_streams=3)
+    P = 8_000
+    nbytes = batch.L.lr_views_workspace_bytes(P, 128, 96, 100_000, 3)
+    batch._ws = torch.full((nbytes,), 0xFF, dtype=torch.uint8, device=hip_device)      # worst-case stale contents
+    batch._ws_key = (P, 100_000)
+    batch.run(cloud["means3D"], cloud["opacities"], cloud["scales"], cloud["rotations"], cloud["shs"], acc)
+    batch.check()
+    assert float(acc["means3D"].abs().max()) > 0
+
+
 def test_view_batch_with_fused_loss_equals_autograd(hip_device):
     """ViewBatch(targets=...) (lr_views_train_accumulate: render -> L1+DSSIM -> backward per view inside one C call)
     == the autograd op followed by luciddreamer_amd.loss.l1_dssim_loss, summed over the views."""

@@ -44,6 +44,43 @@ def test_render_entry_contract(hip_device):
     hp.compare_forward(hip, ref)
 
 
+def test_render_python_sh_and_python_cov_branches(hip_device):
+    """opt.convert_SHs_python / opt.compute_cov3D_python (gaussian_renderer/__init__.py:62-63, 73-78): colours and
+    covariances computed in torch and fed as colors_precomp / cov3D_precomp give the image of the in-kernel route, and
+    the parameter gradients agree (the SH / covariance chain rule then runs in torch autograd)."""
+    from types import SimpleNamespace
+    c = synthetic.make_cloud(15_000, "box", 7)
+    cam = cameras.identity_camera(256, 160).to(hip_device)
+    bg = torch.tensor([0.1, 0.2, 0.3], device=hip_device)
+    g = synthetic.upstream_grad(160, 256).to(hip_device)
+
+    def build_rotation(q):                                   # R/utils/general.py:78-100
+        q = torch.nn.functional.normalize(q)
+        r, x, y, z = q.unbind(1)
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).view(-1, 3, 3)
+
+    class PC(GaussianCloud):
+        def get_covariance(self, scaling_modifier=1):        # R/scene/gaussian_model.py:29-33, 119-120
+            L = build_rotation(self._rotation) * (scaling_modifier * self.get_scaling)[:, None, :]
+            S = L @ L.transpose(1, 2)
+            return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], 1)
+
+    outs = {}
+    for name, opt in (("kernel", SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)),
+                      ("python", SimpleNamespace(debug=False, compute_cov3D_python=True, convert_SHs_python=True))):
+        pc = PC(c["means3D"].to(hip_device), c["scales"].to(hip_device), c["rotations"].to(hip_device),
+                c["opacities"].to(hip_device), c["shs"].to(hip_device), active_sh_degree=3)
+        pkg = render(cam, pc, opt, bg)
+        (pkg["render"] * g).sum().backward()
+        outs[name] = (pkg["render"].detach(), [p.grad.clone() for p in pc.parameters()], pkg["radii"])
+    assert torch.equal(outs["kernel"][2], outs["python"][2])
+    assert float((outs["kernel"][0] - outs["python"][0]).abs().max()) <= 2e-5
+    for a, b in zip(outs["kernel"][1], outs["python"][1]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-12
+
+
 class _OracleRasterize(torch.autograd.Function):
     """The CPU oracle as an autograd op (test infrastructure) so the same torch optimiser can drive both paths."""
 
