@@ -23,7 +23,8 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe
 SOURCES = {
     # bit-exact projection / conic / radius vs the CPU oracle: no FMA contraction in this TU
     "preprocess.hip": ["-ffp-contract=off"],
-    "binning.hip": [],
+    "binning.hip": [],          # the generic radix sort (simple-knn's Morton order)
+    "tilebin.hip": [],          # compaction, tile partition, per-tile sort
     # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
     "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": ["-fno-slp-vectorize"],

@@ -44,9 +44,9 @@ int fail(int code, const std::string& msg)
     } while (0)
 
 // ---- optional per-stage HIP-event timing (used by bench.py for the roofline figures) ----------
-enum Stage { ST_PREPROCESS = 0, ST_COMPACT, ST_DEPTH_SORT, ST_SCAN, ST_EMIT, ST_TILE_SORT, ST_RANGES, ST_RENDER_FWD,
+enum Stage { ST_PREPROCESS = 0, ST_COMPACT, ST_BIN_COUNT, ST_BIN_SCAN, ST_BIN_SCATTER, ST_TILE_SORT, ST_RENDER_FWD,
              ST_GRAD_ZERO, ST_RENDER_BWD, ST_OUT_ZERO, ST_GAUSS_BWD, ST_COUNT };
-const char* const kStageNames[ST_COUNT] = { "preprocess", "compact", "depth_sort", "scan", "emit", "tile_sort", "ranges",
+const char* const kStageNames[ST_COUNT] = { "preprocess", "compact", "bin_count", "bin_scan", "bin_scatter", "tile_sort",
                                             "render_fwd", "grad_zero", "render_bwd", "out_zero", "gauss_bwd" };
 struct ProfRec { int stage; hipEvent_t e0, e1; };
 bool g_prof_on = false;
@@ -73,6 +73,21 @@ struct ProfScope {
     ~ProfScope()
     {
         if (on) { (void)hipEventRecord(r.e1, s); std::lock_guard<std::mutex> lock(g_prof_mu); g_prof_recs.push_back(r); }
+    }
+};
+
+// stage boundaries inside launch_tile_binning: boundary i closes stage i-1 and opens stage i of
+// {bin_count, bin_scan, bin_scatter, tile_sort}
+struct BinProf : lr::TileBinTimes {
+    ProfRec cur; bool open = false;
+    void mark(int boundary, hipStream_t s) override
+    {
+        if (!g_prof_on) return;
+        if (open) { (void)hipEventRecord(cur.e1, s); std::lock_guard<std::mutex> lock(g_prof_mu); g_prof_recs.push_back(cur); open = false; }
+        if (boundary < 4) {
+            cur.stage = ST_BIN_COUNT + boundary; cur.e0 = prof_event(); cur.e1 = prof_event();
+            (void)hipEventRecord(cur.e0, s); open = true;
+        }
     }
 };
 
@@ -133,18 +148,18 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
     GaussRec* rec = reinterpret_cast<GaussRec*>(geom + GL.rec);
     uint8_t* clamped = reinterpret_cast<uint8_t*>(geom + GL.clamped);
     uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + GL.tiles_touched);
-    uint32_t* gkey_a = reinterpret_cast<uint32_t*>(geom + GL.key_a);
-    uint32_t* gkey_b = reinterpret_cast<uint32_t*>(geom + GL.key_b);
-    uint32_t* gval_a = reinterpret_cast<uint32_t*>(geom + GL.val_a);
-    uint32_t* gval_b = reinterpret_cast<uint32_t*>(geom + GL.val_b);
-    uint32_t* offsets = reinterpret_cast<uint32_t*>(geom + GL.offsets);
-    uint2* scan_sums = reinterpret_cast<uint2*>(geom + GL.scan_sums);
-    uint32_t* ghist = reinterpret_cast<uint32_t*>(geom + GL.hist);
     uint32_t* tiles_ref = reinterpret_cast<uint32_t*>(geom + GL.tiles_ref);
+    uint32_t* vis_list = reinterpret_cast<uint32_t*>(geom + GL.vis_list);
+    uint32_t* offsets = reinterpret_cast<uint32_t*>(geom + GL.offsets);
     uint32_t* goff = reinterpret_cast<uint32_t*>(geom + GL.goff);
+    uint4* scan_sums = reinterpret_cast<uint4*>(geom + GL.scan_sums);
     float* final_T = reinterpret_cast<float*>(img + IL.final_T);
     uint32_t* n_contrib = reinterpret_cast<uint32_t*>(img + IL.n_contrib);
     uint2* ranges = reinterpret_cast<uint2*>(img + IL.ranges);
+    uint32_t* part_hist = reinterpret_cast<uint32_t*>(img + IL.part_hist);
+    uint32_t* bin_total = reinterpret_cast<uint32_t*>(img + IL.bin_total);
+    uint32_t* bin_start = reinterpret_cast<uint32_t*>(img + IL.bin_start);
+    uint32_t* big_queue = reinterpret_cast<uint32_t*>(img + IL.big_queue);
 
     // header starts zeroed; the preprocess kernel fills in {capacity, P}
     LR_HIP_CHECK(hipMemsetAsync(hdr, 0, offsetof(GeomHeader, sticky_overflow), s));
@@ -161,36 +176,21 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
     long long R_bound = 0;
     int num_rendered = 0;
     uint32_t* point_list = nullptr;
-    uint32_t* inst_keys_sorted = nullptr;
     uint32_t* inst_gid = nullptr;
-    // which ping-pong half ends up holding the tile-sorted list: a pure function of the tile count
-    const int tile_bits = bits_for((uint32_t)(num_tiles - 1));
-    const int tile_passes = (tile_bits + RADIX_BITS - 1) / RADIX_BITS;
+    bool ranges_written = false;
 
     if (P > 0) {
-        // K1: cull / project / conic / colour -> GaussRec, radii, tile counts, depth keys
+        // K1: cull / project / conic / colour -> GaussRec, radii, tile counts
         { ProfScope ps(ST_PREPROCESS, s);
         launch_preprocess(vp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          prefiltered != 0, radii, rec, clamped, tiles_touched, tiles_ref, gkey_a, hdr,
+                          prefiltered != 0, radii, rec, clamped, tiles_touched, tiles_ref, nullptr, hdr,
                           (uint32_t)binning_capacity, s); }
         LR_DEBUG_SYNC(debug, s, "preprocess");
 
-        // compact the Gaussians that emit anything (index order kept), then depth-sort only those
-        // (stable, value = Gaussian index)
+        // one scan in index order: the emitting Gaussians, their first instance slots, every count of the header
         { ProfScope ps(ST_COMPACT, s);
-        launch_compact(P, tiles_touched, tiles_ref, gkey_a, scan_sums, gkey_b, gval_b, hdr, s); }
+        launch_compact(P, tiles_touched, tiles_ref, scan_sums, vis_list, offsets, goff, hdr, s); }
         LR_DEBUG_SYNC(debug, s, "compact");
-        uint32_t *sorted_depth_keys, *order;
-        { ProfScope ps(ST_DEPTH_SORT, s);
-        radix_sort_pairs(gkey_b, gkey_a, gval_b, gval_a, /*iota*/ false, &hdr->num_compact, P, 32, ghist, &sorted_depth_keys,
-                         &order, s); }
-        (void)sorted_depth_keys;
-        LR_DEBUG_SYNC(debug, s, "depth sort");
-
-        // exclusive scan of tile counts in depth order; total -> header
-        { ProfScope ps(ST_SCAN, s);
-        launch_scan_tiles(P, order, tiles_touched, tiles_ref, offsets, scan_sums, hdr, s); }
-        LR_DEBUG_SYNC(debug, s, "scan");
 
         if (binning_capacity == 0) {
             // exact mode: one small read-back, like rasterizer_impl.cu:281-282: the reference's num_rendered
@@ -209,39 +209,25 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
         const BinLayout BL = bin_layout(R_bound);
         char* bin = binning_alloc(BL.total, binning_user);
         if (!bin) return fail(LR_ERR_ALLOC, "binning allocator returned NULL");
-        uint32_t* bkey_a = reinterpret_cast<uint32_t*>(bin + BL.key_a);
-        uint32_t* bkey_b = reinterpret_cast<uint32_t*>(bin + BL.key_b);
-        uint32_t* bval_a = reinterpret_cast<uint32_t*>(bin + BL.val_a);
-        uint32_t* bval_b = reinterpret_cast<uint32_t*>(bin + BL.val_b);
-        uint32_t* bhist = reinterpret_cast<uint32_t*>(bin + BL.hist);
+        point_list = reinterpret_cast<uint32_t*>(bin + BL.point_list);
         inst_gid = reinterpret_cast<uint32_t*>(bin + BL.inst_gid);
-
-        // emit into the half from which `tile_passes` ping-pong passes end in (key_a, val_a)
-        uint32_t* ekey = (tile_passes & 1) ? bkey_b : bkey_a;
-        uint32_t* eval = (tile_passes & 1) ? bval_b : bval_a;
-        uint32_t* okey = (tile_passes & 1) ? bkey_a : bkey_b;
-        uint32_t* oval = (tile_passes & 1) ? bval_a : bval_b;
         if (R_bound > 0) {
-            { ProfScope ps(ST_EMIT, s);
-            launch_emit(P, gx, gy, order, offsets, tiles_touched, rec, radii, hdr, (uint32_t)R_bound, ekey, inst_gid, goff, s); }
-            LR_DEBUG_SYNC(debug, s, "emit");
-            // stable partition by tile id: with the depth order of emission this is the reference's
-            // (tile | depth) order (rasterizer_impl.cu:301-309)
-            { ProfScope ps(ST_TILE_SORT, s);
-            radix_sort_pairs(ekey, okey, eval, oval, /*iota: the values are emission indices*/ true, &hdr->num_sorted, R_bound, tile_bits,
-                             bhist, &inst_keys_sorted, &point_list, s); }
-            LR_DEBUG_SYNC(debug, s, "tile sort");
-        } else {
-            inst_keys_sorted = bkey_a;
-            point_list = bval_a;
+            // count -> scan -> scatter -> per-tile sort (tilebin.hip): the reference's (tile | depth) order
+            // (rasterizer_impl.cu:301-309) and the tile ranges (:116-138)
+            BinProf bp;
+            const int rc = launch_tile_binning(P, gx, gy, bits_for((uint32_t)(R_bound - 1)), vis_list, offsets, tiles_touched, rec,
+                                               radii, hdr, part_hist, bin_total, bin_start, big_queue, inst_gid,
+                                               reinterpret_cast<unsigned long long*>(bin + BL.words), point_list, ranges,
+                                               &bp, s);
+            if (rc == -2) return fail(LR_ERR_INVALID_ARG, "image / instance count too large: tile and slot bits exceed the 64-bit sort word");
+            if (rc != 0) return fail(LR_ERR_HIP, "could not reserve LDS for the binning kernels");
+            ranges_written = true;
+            LR_DEBUG_SYNC(debug, s, "tile binning");
         }
-        { ProfScope ps(ST_RANGES, s);
-        launch_ranges(inst_keys_sorted, hdr, R_bound, num_tiles, ranges, s); }
-        LR_DEBUG_SYNC(debug, s, "ranges");
     } else {
         (void)binning_alloc(bin_layout(0).total, binning_user);
-        LR_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)num_tiles * sizeof(uint2), s));
     }
+    if (!ranges_written) LR_HIP_CHECK(hipMemsetAsync(ranges, 0, (size_t)num_tiles * sizeof(uint2), s));
 
     // K6: blend
     { ProfScope ps(ST_RENDER_FWD, s);
@@ -328,7 +314,7 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
     const uint8_t* clamped = reinterpret_cast<const uint8_t*>(geom_buffer + GL.clamped);
     const uint32_t* tiles_touched = reinterpret_cast<const uint32_t*>(geom_buffer + GL.tiles_touched);
     const uint32_t* goff = reinterpret_cast<const uint32_t*>(geom_buffer + GL.goff);
-    const uint32_t* vis_list = reinterpret_cast<const uint32_t*>(geom_buffer + GL.tiles_ref);   // see launch_compact
+    const uint32_t* vis_list = reinterpret_cast<const uint32_t*>(geom_buffer + GL.vis_list);
     const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(geom_buffer + GL.header);
     const float* final_T = reinterpret_cast<const float*>(image_buffer + IL.final_T);
     const uint32_t* n_contrib = reinterpret_cast<const uint32_t*>(image_buffer + IL.n_contrib);

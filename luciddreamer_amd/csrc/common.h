@@ -78,53 +78,66 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 
+// ---- tile binning geometry (tilebin.hip) -----------------------------------------------------
+constexpr int PART_BINS_MAX = 16384;        // partition bins: one 4-byte LDS counter each (64 KB)
+constexpr int PART_BLOCKS_MAX = 256;        // workgroups of the count / scatter kernels (rows of the histogram)
+constexpr int PART_THREADS = 1024;
+constexpr int PART_MIN_GAUSS = 1024;        // emitting Gaussians per workgroup before another workgroup is used
+constexpr int TSORT_THREADS = 256;
+constexpr int TSORT_LDS = 2048;             // bin entries the per-bin sort keeps in LDS (16 KB)
+constexpr int TSORT_BIG_LDS = 16384;        // ... the large-bin kernel (128 KB); beyond: in place in global memory
+constexpr int TSORT_BIG_BLOCKS = 64;
+struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)
+PartPlan part_plan(int num_tiles);
+
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, key_a, key_b, val_a, val_b, offsets, scan_sums, hist, goff, tiles_ref, total;
+    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, goff, tiles_ref, vis_list, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
     L.header = o;        o += align_up(sizeof(GeomHeader));
     L.rec = o;           o += align_up(Pz * sizeof(GaussRec));
     L.clamped = o;       o += align_up(Pz);
-    L.tiles_touched = o; o += align_up(Pz * 4);
-    L.key_a = o;         o += align_up(Pz * 4);
-    L.key_b = o;         o += align_up(Pz * 4);
-    L.val_a = o;         o += align_up(Pz * 4);
-    L.val_b = o;         o += align_up(Pz * 4);
-    L.offsets = o;       o += align_up(Pz * 4);
-    L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 8);
-    L.hist = o;          o += sort_hist_bytes((long long)Pz);
-    L.goff = o;          o += align_up(Pz * 4);
-    L.tiles_ref = o;     o += align_up(Pz * 4);      // after compaction: vis_list (ids of emitting Gaussians, index order)
+    L.tiles_touched = o; o += align_up(Pz * 4);      // instances each Gaussian emits (after exact tile culling)
+    L.tiles_ref = o;     o += align_up(Pz * 4);      // the reference's rectangle areas (their sum is num_rendered)
+    L.vis_list = o;      o += align_up(Pz * 4);      // ids of the emitting Gaussians, index order (num_compact entries)
+    L.offsets = o;       o += align_up(Pz * 4);      // first instance slot of vis_list[k]
+    L.goff = o;          o += align_up(Pz * 4);      // the same, indexed by Gaussian id
+    L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 16);
     L.total = o;
     return L;
 }
-struct ImgLayout { size_t final_T, n_contrib, ranges, total; };
+struct ImgLayout { size_t final_T, n_contrib, ranges, part_hist, bin_total, bin_start, big_queue, total; };
 inline ImgLayout img_layout(int W, int H) {
     ImgLayout L; size_t o = 0; size_t N = (size_t)W * H; if (N == 0) N = 1;
     size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y); if (T == 0) T = 1;
+    // partition bins (tilebin.hip part_plan, restated here so that the header-only layout needs no library call)
+    size_t shift = 0;
+    while (((T - 1) >> shift) + 1 > (size_t)PART_BINS_MAX) shift++;
+    const size_t bins = ((T - 1) >> shift) + 1;
     L.final_T = o;   o += align_up(N * 4);
     L.n_contrib = o; o += align_up(N * 4);
     L.ranges = o;    o += align_up(T * 8);
+    L.part_hist = o; o += align_up((size_t)PART_BLOCKS_MAX * bins * 4);   // per-workgroup bin counts -> bases
+    L.bin_total = o; o += align_up(bins * 4);
+    L.bin_start = o; o += align_up(bins * 4);
+    L.big_queue = o; o += align_up((bins + 1) * 4);
     L.total = o;
     return L;
 }
-struct BinLayout { size_t key_a, key_b, val_a, val_b, hist, inst_gid, inst_grad, total; };
+struct BinLayout { size_t point_list, words, inst_gid, inst_grad, total; };
 __host__ __device__ inline BinLayout bin_layout(long long R) {
-    // val_a sits at offset 0 and always receives the final tile-sorted list (the emit target is chosen by
-    // the parity of the number of sort passes).  The list holds EMISSION indices e; inst_gid[e] is the
-    // Gaussian and inst_grad[e] the slot the blend backward writes that instance's nine partial sums to
-    // (one plain 48-byte store per tile instance instead of nine global atomics).  The backward resolves
-    // the R-dependent offsets on the device from GeomHeader::bin_bound.
+    // point_list sits at offset 0: the tile-sorted list of EMISSION slots e; inst_gid[e] is the Gaussian and
+    // inst_grad[e] the slot the blend backward writes that instance's nine partial sums to (one plain 48-byte
+    // store per tile instance instead of nine global atomics).  `words` holds the 64-bit [sub-tile | depth | slot]
+    // sort words between the scatter and the per-bin sort.  The backward resolves the R-dependent offsets on the
+    // device from GeomHeader::bin_bound.
     BinLayout L; size_t o = 0; size_t Rz = R > 0 ? (size_t)R : 1;
-    L.val_a = o; o += align_up(Rz * 4);
-    L.val_b = o; o += align_up(Rz * 4);
-    L.key_a = o; o += align_up(Rz * 4);
-    L.key_b = o; o += align_up(Rz * 4);
-    L.hist = o;  o += sort_hist_bytes((long long)Rz);
-    L.inst_gid = o;  o += align_up(Rz * 4);
-    L.inst_grad = o; o += align_up(Rz * sizeof(GradRec));
+    L.point_list = o; o += align_up(Rz * 4);
+    L.words = o;      o += align_up(Rz * 8);
+    L.inst_gid = o;   o += align_up(Rz * 4);
+    L.inst_grad = o;  o += align_up(Rz * sizeof(GradRec));
     L.total = o;
     return L;
 }
@@ -228,19 +241,20 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
                       const uint32_t* n_dev, long long n_bound, int end_bit, uint32_t* hist,
                       uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
 
-// Order-preserving compaction of the Gaussians with tiles_touched != 0: (ckey, cidx) <- (depth_key, index);
-// count -> hdr->num_compact, sum of tiles_ref over all Gaussians -> hdr->num_rendered.
-void launch_compact(int P, const uint32_t* tiles_touched, uint32_t* tiles_ref, const uint32_t* depth_key,
-                    uint2* block_sums, uint32_t* ckey, uint32_t* cidx, GeomHeader* hdr, hipStream_t s);
-// offsets[k] = exclusive prefix of tiles_touched[order[k]], k in depth order; total -> hdr->num_instances
-// (and the overflow flag against hdr->capacity); sum of tiles_ref -> hdr->num_rendered (reference count).
-void launch_scan_tiles(int P, const uint32_t* order, const uint32_t* tiles_touched, const uint32_t* tiles_ref,
-                       uint32_t* offsets, uint2* block_sums, GeomHeader* hdr, hipStream_t s);
-void launch_emit(int P, int gx, int gy, const uint32_t* order, const uint32_t* offsets,
-                 const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
-                 uint32_t bin_bound, uint32_t* inst_keys, uint32_t* inst_gid, uint32_t* goff, hipStream_t s);
-void launch_ranges(const uint32_t* sorted_keys, const GeomHeader* hdr, long long n_bound, int num_tiles,
-                   uint2* ranges, hipStream_t s);
+// Order-preserving compaction of the Gaussians with tiles_touched != 0 (vis_list) fused with the exclusive scan of their
+// instance counts (offsets by rank, goff by Gaussian id); fills every count of the header: num_compact, num_rendered
+// (the reference's: sum of tiles_ref over all Gaussians), num_instances, num_sorted, overflow, bin_bound.
+void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, uint4* block_sums,
+                    uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s);
+// optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
+struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };
+// count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1
+// (LDS attribute) or -2 (sub-tile + depth + slot bits exceed 64).
+int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
+                        const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
+                        uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
+                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
+                        TileBinTimes* t, hipStream_t s);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per
 // tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue

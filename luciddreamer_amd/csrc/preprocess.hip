@@ -168,7 +168,8 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         const bool pass = in_range && !(vz1 <= 0.2f);
         if (in_range && !pass) {
             if (prefiltered) hdr->prefilter_trap = 1;
-            radii[gid] = 0; tiles_touched[gid] = 0; tiles_ref[gid] = 0; depth_key[gid] = 0xFFFFFFFFu;
+            radii[gid] = 0; tiles_touched[gid] = 0; tiles_ref[gid] = 0;
+            if (depth_key) depth_key[gid] = 0xFFFFFFFFu;
         }
         const uint64_t m = __ballot(pass);
         const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -310,7 +311,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
     radii[idx] = radius_out;
     tiles_touched[idx] = tiles_out;
     tiles_ref[idx] = area_ref;
-    depth_key[idx] = key_out;
+    if (depth_key) depth_key[idx] = key_out;
 }
 
 __global__ void __launch_bounds__(256)

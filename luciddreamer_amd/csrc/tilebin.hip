@@ -1,0 +1,494 @@
+// tilebin.hip -- tile binning for gfx950: from per-Gaussian tile counts to depth-ordered per-tile instance lists.
+//
+// Replaces cub::DeviceScan::InclusiveSum (rasterizer_impl.cu:278), duplicateWithKeys (:70-111),
+// cub::DeviceRadixSort::SortPairs on 64-bit [tile | depth] keys (:304-309) and identifyTileRanges (:116-138).
+//
+// Required invariant (what the reference's stable 64-bit sort produces): inside every tile the instances are
+// ordered by (float bits of view depth ascending, Gaussian index ascending).
+//
+// MI355X design (round 2; the round-1 pipeline sorted the Gaussians globally by depth with 4 radix passes, emitted
+// in depth order and stably partitioned by tile with 2 more: 21 launches, 0.19 ms per C3 view for ~47 MB of bytes):
+//
+//   k_compact_reduce / k_compact_write   one scan over the P Gaussians gives, in INDEX order, the list of emitting
+//                                        Gaussians (vis_list), each one's first instance slot (offsets / goff) and
+//                                        every count of the header.  Instance slots are therefore contiguous per
+//                                        Gaussian and ascending with the Gaussian index.
+//   k_part<COUNT>                        a few hundred large workgroups each walk a contiguous chunk of vis_list, run the
+//                                        exact tile test of every rectangle tile and histogram the hits over the
+//                                        partition bins in LDS (one bin per tile up to 16384 tiles; 2^s neighbouring
+//                                        tiles per bin beyond that).  Integer LDS atomics: counts are order-free.
+//   k_part_scan1 / k_part_scan2          per-bin prefix over the workgroups, prefix over the bins -> bin start, and
+//                                        the per-tile ranges directly (no identifyTileRanges pass, no memset).
+//   k_part<SCATTER>                      the same walk again; every hit takes the next free position of its bin from
+//                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
+//                                        The order inside a bin at this point is arbitrary -- and irrelevant:
+//   k_tile_sort / k_tile_sort_big        one workgroup per bin sorts its words in LDS (bitonic network; > 2048 entries:
+//                                        a second kernel with 128 KB of LDS, > 16384: in place in global memory).
+//                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
+//                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
+//                                        repeatable, whatever order the scatter produced.
+//
+// 9 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
+// atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
+#include "common.h"
+
+namespace lr {
+
+namespace {
+
+__device__ __forceinline__ uint64_t lanemask_lt()
+{
+    const uint32_t lane = threadIdx.x & 63;
+    return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+
+__device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t t = 0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += s_tmp[i];
+    __syncthreads();
+    return t;
+}
+
+// -------------------------------------------------------------------------------------------
+// compaction + instance offsets, index order (2 kernels).  block_sums[b] = {emitting Gaussians, instances,
+// reference rectangle areas} of block b.
+// -------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_compact_reduce(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ tiles_ref,
+                 uint4* __restrict__ block_sums)
+{
+    __shared__ uint32_t s_tmp[4];
+    const int base = blockIdx.x * SCAN_TILE;
+    uint32_t cnt = 0, inst = 0, sum_ref = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int k = base + i * SCAN_THREADS + threadIdx.x;
+        if (k < P) { const uint32_t t = tiles_touched[k]; cnt += t != 0 ? 1u : 0u; inst += t; sum_ref += tiles_ref[k]; }
+    }
+    cnt = block_reduce_sum(cnt, s_tmp);
+    inst = block_reduce_sum(inst, s_tmp);
+    sum_ref = block_reduce_sum(sum_ref, s_tmp);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(cnt, inst, sum_ref, 0u);
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS)
+k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
+                uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
+                GeomHeader* hdr)
+{
+    __shared__ uint32_t s_tmp[4];
+    __shared__ uint32_t s_wc[4], s_wi[4];
+    const bool last_block = blockIdx.x == gridDim.x - 1;
+    uint32_t pre_c = 0, pre_i = 0, ref_total = 0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += SCAN_THREADS) {
+        const uint4 v = block_sums[i];
+        if (i < (int)blockIdx.x) { pre_c += v.x; pre_i += v.y; }
+        ref_total += v.z;
+    }
+    pre_c = block_reduce_sum(pre_c, s_tmp);
+    pre_i = block_reduce_sum(pre_i, s_tmp);
+    if (last_block) ref_total = block_reduce_sum(ref_total, s_tmp);
+    // blocked arrangement keeps index order: thread t owns SCAN_ITEMS consecutive Gaussians
+    const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    uint32_t tt[SCAN_ITEMS];
+    uint32_t sum_c = 0, sum_i = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int k = base + i;
+        tt[i] = (k < P) ? tiles_touched[k] : 0u;
+        sum_c += tt[i] != 0 ? 1u : 0u;
+        sum_i += tt[i];
+    }
+    uint32_t inc_c = sum_c, inc_i = sum_i;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t a = __shfl_up(inc_c, off), b = __shfl_up(inc_i, off);
+        if ((int)(threadIdx.x & 63) >= off) { inc_c += a; inc_i += b; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) { s_wc[w] = inc_c; s_wi[w] = inc_i; }
+    __syncthreads();
+    uint32_t wb_c = 0, wb_i = 0;
+    for (int i = 0; i < w; i++) { wb_c += s_wc[i]; wb_i += s_wi[i]; }
+    uint32_t run_c = pre_c + wb_c + inc_c - sum_c;
+    uint32_t run_i = pre_i + wb_i + inc_i - sum_i;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        if (tt[i]) {
+            vis_list[run_c] = (uint32_t)(base + i);
+            offsets[run_c] = run_i;
+            goff[base + i] = run_i;            // where this Gaussian's instance slots start
+            run_c++;
+            run_i += tt[i];
+        }
+    }
+    if (last_block && threadIdx.x == SCAN_THREADS - 1) {
+        const uint32_t total = run_i;
+        hdr->num_compact = run_c;
+        hdr->num_rendered = ref_total;          // the reference's count (sum of rectangle areas)
+        hdr->num_instances = total;             // after exact tile culling: what is binned
+        const bool over = (hdr->capacity != 0 && total > hdr->capacity);
+        hdr->overflow = over ? 1u : 0u;
+        if (over) hdr->sticky_overflow = 1u;
+        hdr->num_sorted = over ? hdr->capacity : total;
+        hdr->bin_bound = hdr->capacity != 0 ? hdr->capacity : total;   // what the binning buffer is laid out for
+    }
+}
+
+// -------------------------------------------------------------------------------------------
+// the walk over a chunk of emitting Gaussians: f(tile, slot, gid, depth_bits) for every (Gaussian, tile) pair that
+// passes the exact tile test, slots consecutive per Gaussian in (y, x) order (rasterizer_impl.cu:85-109).
+// Rectangles of up to SMALL tiles are walked by their own lane, larger ones by the whole wave.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_rect_dev(float px, float py, int radius, int gx, int gy,
+                                              int& minx, int& miny, int& maxx, int& maxy)
+{
+    minx = min(gx, max(0, (int)((px - radius) / TILE_X)));
+    miny = min(gy, max(0, (int)((py - radius) / TILE_Y)));
+    maxx = min(gx, max(0, (int)((px + radius + TILE_X - 1) / TILE_X)));
+    maxy = min(gy, max(0, (int)((py + radius + TILE_Y - 1) / TILE_Y)));
+}
+
+// workgroups of the partition kernels and the compact ranks [beg, end) of workgroup b: a pure function of the
+// device-side count, evaluated identically by the count, scan and scatter kernels
+__device__ __forceinline__ int part_active_blocks(uint32_t V)
+{
+    const uint32_t nb = (V + PART_MIN_GAUSS - 1) / PART_MIN_GAUSS;
+    return (int)(nb < 1u ? 1u : (nb > (uint32_t)PART_BLOCKS_MAX ? (uint32_t)PART_BLOCKS_MAX : nb));
+}
+__device__ __forceinline__ void part_chunk(uint32_t V, int nb, int b, uint32_t& beg, uint32_t& end)
+{
+    uint32_t per = (V + (uint32_t)nb - 1) / (uint32_t)nb;
+    per = (per + 63u) & ~63u;
+    beg = (uint32_t)b * per;
+    end = beg + per;
+    if (beg > V) beg = V;
+    if (end > V) end = V;
+}
+
+template <class F>
+__device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, int gy, const uint32_t* __restrict__ vis_list,
+                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+                                           const GaussRec* __restrict__ rec, const int* __restrict__ radii, F f)
+{
+    constexpr uint32_t SMALL = 20;
+    const int lane = threadIdx.x & 63;
+    const uint64_t lt = lanemask_lt();
+    for (uint32_t k0 = beg; k0 < end; k0 += PART_THREADS) {          // beg, end are multiples of 64 or the list end
+        const uint32_t k = k0 + threadIdx.x;
+        uint32_t idx = 0, tt = 0, off = 0, area = 0, dbits = 0;
+        int minx = 0, miny = 0, maxx = 0, maxy = 0;
+        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, qmax = 0.f, r_c = 0.f, r_a = 0.f;
+        if (k < end) {
+            idx = vis_list[k];
+            tt = tiles_touched[idx];                 // > 0 for every entry of vis_list
+            off = offsets[k];
+            const float4* g = reinterpret_cast<const float4*>(rec + idx);
+            const float4 q0 = g[0];
+            const float4 q1 = g[1];
+            const float4 q2 = g[2];
+            mx = q0.x; my = q0.y; ca = q0.z; cb = q0.w; cc = q1.x;
+            dbits = __float_as_uint(q2.y);           // view depth > 0.2: bit 31 clear, bit order == float order
+            qmax = q2.z;
+            r_c = -cb / cc; r_a = -cb / ca;
+            tile_rect_dev(mx, my, radii[idx], gx, gy, minx, miny, maxx, maxy);
+            area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
+        }
+        const int rw = maxx - minx;
+        const bool culled = area <= CULL_MAX_TILES;   // same rule as the count in k_preprocess
+        if (tt != 0 && area <= SMALL) {
+            uint32_t o = off;
+            for (int y = miny; y < maxy; y++)
+                for (int x = minx; x < maxx; x++)
+                    if (tile_hit(mx, my, ca, cb, cc, r_c, r_a, qmax, x, y)) { f((uint32_t)(y * gx + x), o, idx, dbits); o++; }
+        }
+        uint64_t big = __ballot(tt != 0 && area > SMALL);
+        while (big) {
+            const int src = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            const uint32_t b_idx = __shfl(idx, src), b_area = __shfl(area, src), b_db = __shfl(dbits, src);
+            uint32_t b_off = __shfl(off, src);
+            const int b_minx = __shfl(minx, src), b_miny = __shfl(miny, src), b_rw = __shfl(rw, src);
+            const bool b_culled = __shfl((int)culled, src) != 0;
+            const float b_mx = __shfl(mx, src), b_my = __shfl(my, src), b_ca = __shfl(ca, src), b_cb = __shfl(cb, src);
+            const float b_cc = __shfl(cc, src), b_qmax = __shfl(qmax, src);
+            const float b_rc = __shfl(r_c, src), b_ra = __shfl(r_a, src);
+            for (uint32_t j0 = 0; j0 < b_area; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                bool hit = j < b_area;
+                int y = 0, x = 0;
+                if (hit) {
+                    y = b_miny + (int)(j / (uint32_t)b_rw); x = b_minx + (int)(j % (uint32_t)b_rw);
+                    if (b_culled) hit = tile_hit(b_mx, b_my, b_ca, b_cb, b_cc, b_rc, b_ra, b_qmax, x, y);
+                }
+                const uint64_t m = __ballot(hit);
+                if (hit) f((uint32_t)(y * gx + x), b_off + (uint32_t)__popcll(m & lt), b_idx, b_db);
+                b_off += (uint32_t)__popcll(m);
+            }
+        }
+    }
+}
+
+// MODE 0: count (per-workgroup bin histogram -> part_hist[b][bin]; also records inst_gid[slot])
+// MODE 1: scatter (64-bit words into their bins)
+template <int MODE>
+__global__ void __launch_bounds__(PART_THREADS)
+k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* __restrict__ vis_list,
+       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
+       const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
+       uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_start, uint32_t* __restrict__ inst_gid,
+       unsigned long long* __restrict__ words)
+{
+    extern __shared__ uint32_t s_bin[];                  // [bins]
+    const uint32_t V = hdr->num_compact;
+    const int nb = part_active_blocks(V);
+    const int b = (int)blockIdx.x;
+    if (b >= nb) return;
+    const uint32_t cap = hdr->num_sorted;                // instances that fit the binning buffer (all, in exact mode)
+    uint32_t* row = part_hist + (size_t)b * bins;
+    if (MODE == 0) {
+        for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[i] = 0u;
+    } else {
+        for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[i] = row[i] + bin_start[i];
+    }
+    __syncthreads();
+    uint32_t beg, end;
+    part_chunk(V, nb, b, beg, end);
+    const uint32_t sub_mask = (1u << sub_shift) - 1u;
+    if (MODE == 0) {
+        walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
+                   [&](uint32_t tile, uint32_t slot, uint32_t gid, uint32_t) {
+                       if (slot < cap) { atomicAdd(&s_bin[tile >> sub_shift], 1u); inst_gid[slot] = gid; }
+                   });
+        __syncthreads();
+        for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[i];
+    } else {
+        walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
+                   [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
+                       if (slot < cap) {
+                           const uint32_t pos = atomicAdd(&s_bin[tile >> sub_shift], 1u);
+                           words[pos] = ((unsigned long long)(tile & sub_mask) << (31 + slot_bits)) |
+                                        ((unsigned long long)dbits << slot_bits) | (unsigned long long)slot;
+                       }
+                   });
+    }
+}
+
+// per bin: exclusive prefix over the active workgroups (in place), total -> bin_total
+__global__ void __launch_bounds__(256)
+k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict__ part_hist, uint32_t* __restrict__ bin_total)
+{
+    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bin >= bins) return;
+    const int nb = part_active_blocks(hdr->num_compact);
+    uint32_t run = 0;
+    for (int b = 0; b < nb; b++) {
+        uint32_t* p = part_hist + (size_t)b * bins + bin;
+        const uint32_t v = *p;
+        *p = run;
+        run += v;
+    }
+    bin_total[bin] = run;
+}
+
+// one workgroup: exclusive prefix over the bins -> bin_start; per-tile ranges when a bin is a tile (sub_shift == 0),
+// zeroed ranges otherwise (k_tile_sort fills them in); resets the queue of large bins
+__global__ void __launch_bounds__(1024)
+k_part_scan2(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
+             uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    if (threadIdx.x == 0) { s_carry = 0; big_queue[0] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < bins; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = (i < bins) ? bin_total[i] : 0u;
+        uint32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(inc, off);
+            if (lane >= off) inc += t;
+        }
+        if (lane == 63) s_wave[w] = inc;
+        __syncthreads();
+        uint32_t wb = s_carry;
+        for (int j = 0; j < w; j++) wb += s_wave[j];
+        const uint32_t start = wb + inc - v;
+        if (i < bins) {
+            bin_start[i] = start;
+            if (sub_shift == 0) ranges[i] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);   // empty: (0,0), :311
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = start + v;
+        __syncthreads();
+    }
+    if (sub_shift != 0)
+        for (int t = threadIdx.x; t < num_tiles; t += 1024) ranges[t] = make_uint2(0u, 0u);
+}
+
+// -------------------------------------------------------------------------------------------
+// sorting one bin.  All comparators ascending (the first step of every merge mirrors the block), so positions
+// >= n behave as +infinity padding without being stored.
+// -------------------------------------------------------------------------------------------
+template <class Sync>
+__device__ __forceinline__ void bitonic_sort(unsigned long long* a, uint32_t n, uint32_t tid, uint32_t nthreads, Sync sync)
+{
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            const bool flip = (j == (k >> 1));
+            for (uint32_t c = tid; c < (m >> 1); c += nthreads) {
+                uint32_t i, l;
+                if (flip) { i = (c / j) * k + (c % j); l = i ^ (k - 1); }     // mirror inside the block of k
+                else { i = ((c / j) * (j << 1)) + (c % j); l = i + j; }
+                if (l < n) {
+                    const unsigned long long x = a[i], y = a[l];
+                    if (x > y) { a[i] = y; a[l] = x; }
+                }
+            }
+            sync();
+        }
+    }
+}
+
+// after the sort: the list entries (slots) and, when a bin holds several tiles, the per-tile ranges
+__device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32_t n, uint32_t start, int bin, int sub_shift,
+                                             int slot_bits, int num_tiles, uint32_t tid, uint32_t nthreads,
+                                             uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+{
+    const unsigned long long slot_mask = (1ull << slot_bits) - 1ull;
+    for (uint32_t i = tid; i < n; i += nthreads) {
+        const unsigned long long w = a[i];
+        point_list[start + i] = (uint32_t)(w & slot_mask);
+        if (sub_shift != 0) {
+            const uint32_t sub = (uint32_t)(w >> (31 + slot_bits));
+            const int tile = (bin << sub_shift) + (int)sub;
+            if (tile < num_tiles) {
+                if (i == 0 || (uint32_t)(a[i - 1] >> (31 + slot_bits)) != sub) ranges[tile].x = start + i;
+                if (i == n - 1 || (uint32_t)(a[i + 1] >> (31 + slot_bits)) != sub) ranges[tile].y = start + i + 1;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TSORT_THREADS)
+k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+            const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
+            uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue)
+{
+    __shared__ unsigned long long s_a[TSORT_LDS];
+    const int bin = (int)blockIdx.x;
+    const uint32_t n = bin_total[bin];
+    if (n == 0) return;
+    if (n > (uint32_t)TSORT_LDS) {                       // rare: handed to k_tile_sort_big
+        if (threadIdx.x == 0) big_queue[1 + atomicAdd(&big_queue[0], 1u)] = (uint32_t)bin;
+        return;
+    }
+    const uint32_t start = bin_start[bin];
+    for (uint32_t i = threadIdx.x; i < n; i += TSORT_THREADS) s_a[i] = words[start + i];
+    __syncthreads();
+    if (n > 1) bitonic_sort(s_a, n, threadIdx.x, TSORT_THREADS, [] { __syncthreads(); });
+    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, TSORT_THREADS, point_list, ranges);
+}
+
+__global__ void __launch_bounds__(1024)
+k_tile_sort_big(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+                const uint32_t* __restrict__ bin_total, unsigned long long* __restrict__ words,
+                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue)
+{
+    extern __shared__ unsigned long long s_big[];        // [TSORT_BIG_LDS]
+    const uint32_t count = big_queue[0];
+    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
+        const int bin = (int)big_queue[1 + q];
+        const uint32_t n = bin_total[bin], start = bin_start[bin];
+        if (n <= (uint32_t)TSORT_BIG_LDS) {
+            for (uint32_t i = threadIdx.x; i < n; i += 1024) s_big[i] = words[start + i];
+            __syncthreads();
+            bitonic_sort(s_big, n, threadIdx.x, 1024, [] { __syncthreads(); });
+            write_sorted(s_big, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024, point_list, ranges);
+        } else {
+            // larger than the LDS: the same network in place in global memory (one workgroup, L2-resident; slow, but a
+            // single tile with more than 16384 splats is slow to blend anyway)
+            unsigned long long* a = words + start;
+            __syncthreads();
+            bitonic_sort(a, n, threadIdx.x, 1024, [] { __threadfence(); __syncthreads(); });
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024, point_list, ranges);
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+PartPlan part_plan(int num_tiles)
+{
+    PartPlan p;
+    p.sub_shift = 0;
+    while (((num_tiles - 1) >> p.sub_shift) + 1 > PART_BINS_MAX) p.sub_shift++;
+    p.bins = num_tiles > 0 ? ((num_tiles - 1) >> p.sub_shift) + 1 : 1;
+    return p;
+}
+
+void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, uint4* block_sums,
+                    uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s)
+{
+    const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
+    hipLaunchKernelGGL(k_compact_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, tiles_ref, block_sums);
+    hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
+                       offsets, goff, hdr);
+}
+
+int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
+                        const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
+                        uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
+                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
+                        TileBinTimes* t, hipStream_t s)
+{
+    static bool attr_done = false;
+    if (!attr_done) {
+        // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort 128 KB
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PART_BINS_MAX * 4) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PART_BINS_MAX * 4) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                TSORT_BIG_LDS * 8) != hipSuccess)
+            return -1;
+        attr_done = true;
+    }
+    const int num_tiles = gx * gy;
+    const PartPlan pp = part_plan(num_tiles);
+    if (pp.sub_shift + 31 + slot_bits > 64) return -2;
+    // workgroups launched: what the largest possible list needs; the kernels retire the surplus from the device count
+    long long nb = ((long long)P + PART_MIN_GAUSS - 1) / PART_MIN_GAUSS;
+    if (nb < 1) nb = 1;
+    if (nb > PART_BLOCKS_MAX) nb = PART_BLOCKS_MAX;
+    const size_t lds = (size_t)pp.bins * 4;
+    if (t) t->mark(0, s);
+    hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
+                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_start, inst_gid, words);
+    if (t) t->mark(1, s);
+    hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + 255) / 256), dim3(256), 0, s, pp.bins, hdr, part_hist, bin_total);
+    hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, s, pp.bins, num_tiles, pp.sub_shift, bin_total, bin_start, ranges,
+                       big_queue);
+    if (t) t->mark(2, s);
+    hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
+                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_start, inst_gid, words);
+    if (t) t->mark(3, s);
+    hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(TSORT_THREADS), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
+                       bin_start, bin_total, words, point_list, ranges, big_queue);
+    hipLaunchKernelGGL(k_tile_sort_big, dim3(TSORT_BIG_BLOCKS), dim3(1024), (size_t)TSORT_BIG_LDS * 8, s, pp.sub_shift, slot_bits,
+                       num_tiles, bin_start, bin_total, words, point_list, ranges, big_queue);
+    if (t) t->mark(4, s);
+    return 0;
+}
+
+}  // namespace lr

@@ -54,7 +54,10 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
         pkg = render(cams_d[k], gm, opt, bg)                                       # :296
         image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
         Ll1 = l1_loss(image, tg[k])                                                # :301-303
-        loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, tg[k]))
+        if opt.lambda_dssim == 0.0:             # L1 only (tests that need run-to-run bit-repeatability: MIOpen may pick
+            loss = Ll1                          # a different convolution algorithm for ssim's grouped conv on a later call)
+        else:
+            loss = (1.0 - opt.lambda_dssim) * Ll1 + opt.lambda_dssim * (1.0 - ssim(image, tg[k]))
         if dg is not None:       # a depth term: enters the loss, contributes no parameter gradient (backward.cu:539-554)
             loss = loss + depth_weight * l1_loss(pkg["depth"], dg[k])
         if on_loss is not None:

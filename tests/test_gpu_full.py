@@ -44,10 +44,10 @@ def _unpack(out, P, W, H):
     ranges = im[2 * _align(4 * N):2 * _align(4 * N) + 8 * T].view(np.uint32).reshape(T, 2)
     n_inst = int(hdr[5])
     b = binning.cpu().numpy()
-    emission = b[:4 * n_inst].view(np.uint32)               # final tile-sorted list (emission indices), offset 0
-    seg = _align(4 * max(int(hdr[7]), 1))                   # hdr[7] = bin_bound the layout was computed for
-    gid_off = 4 * seg + _align(1024 * 256 * 4 + 256 * 4)    # val_a, val_b, key_a, key_b, histogram scratch
-    inst_gid = b[gid_off:gid_off + 4 * max(int(hdr[7]), 1)].view(np.uint32)
+    emission = b[:4 * n_inst].view(np.uint32)               # final tile-sorted list (emission slots), offset 0
+    Rb = max(int(hdr[7]), 1)                                # hdr[7] = bin_bound the layout was computed for
+    gid_off = _align(4 * Rb) + _align(8 * Rb)               # point_list, 64-bit sort words, then inst_gid
+    inst_gid = b[gid_off:gid_off + 4 * Rb].view(np.uint32)
     point_list = inst_gid[emission]                         # Gaussian index of every list entry
     return dict(rec=rec, final_T=final_T, n_contrib=n_contrib, ranges=ranges, point_list=point_list, hdr=hdr)
 

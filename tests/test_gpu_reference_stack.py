@@ -57,14 +57,17 @@ def test_unchanged_reference_loop_small_with_densification(hip_device):
             res[be]["scaling0"] = gm._scaling.detach().cpu()
     a, b = res["ours"], res["port"]
     assert len(set(b["P"].tolist())) > 1, "densification should change P"
-    # densify_and_prune thresholds accumulated statistics (grad >= 2e-4, opacity < 0.005): a Gaussian sitting on a
-    # threshold can fall either way under 1e-7 differences, after which the two runs hold slightly different sets
-    relP = np.abs(a["P"] - b["P"]) / b["P"]
+    # Up to the first densification (iteration 10) the two runs are the same computation.  densify_and_split then draws
+    # torch.normal samples -- from the device generator in one run, the host generator in the other -- and thresholds
+    # accumulated statistics, so from there on the runs hold different (equally valid) sets of Gaussians: only their
+    # statistics are compared.
     rel = np.abs(a["loss"] - b["loss"]) / b["loss"]
+    relP = np.abs(a["P"] - b["P"]) / b["P"]
     print("small loop: P", b["P"][0], "->", b["P"][-1], "(device", a["P"][-1], ") loss", b["loss"][0], "->", b["loss"][-1],
-          "max rel loss distance", rel.max(), "max rel P distance", relP.max())
-    assert np.array_equal(a["P"][:9], b["P"][:9]) and relP.max() < 0.02
-    assert b["loss"][-1] < b["loss"][0] and rel.max() < 5e-3
+          "max rel loss distance before the first split", rel[:10].max(), "after", rel.max(), "max rel P distance", relP.max())
+    assert np.array_equal(a["P"][:9], b["P"][:9]) and abs(int(a["P"][9]) - int(b["P"][9])) <= 3 and relP.max() < 0.03
+    assert rel[:10].max() < 1e-4 and rel.max() < 0.05
+    assert b["loss"][-1] < b["loss"][0] and a["loss"][-1] < a["loss"][0]
 
 
 def test_c5_at_size_loss_curve_parity(hip_device):
@@ -108,10 +111,12 @@ def test_c5_at_size_loss_curve_parity(hip_device):
         for it, (k, loss_dev, cloud, image_dev) in sorted(probes.items()):
             o = hp.run_oracle(cloud, cams[k], 3, torch.zeros(3))
             img, dep = torch.from_numpy(o["color"]), torch.from_numpy(o["depth"])
+            frag = torch.from_numpy((o["res"].stage()["fragile"] & 1) != 0)
+            assert int(frag.sum()) <= 5e-4 * W * H, int(frag.sum())
             loss_host = 0.8 * R.loss.l1_loss(img, targets[k]) + 0.2 * (1.0 - R.loss.ssim(img, targets[k])) \
                 + 0.1 * R.loss.l1_loss(dep, depths[k])
             worst_probe = max(worst_probe, abs(float(loss_host) - loss_dev) / float(loss_host))
-            assert float((img - image_dev).abs().max()) <= 5e-5, it       # 1e-5 bar + fragile pixels are not masked here
+            assert float((img - image_dev).abs()[:, ~frag].max()) <= hp.COLOR_ATOL, it
     rel = np.abs(a["loss"][:host_iters] - b["loss"]) / b["loss"]
     print(f"C5 at size: device {iters} iterations in {t_dev:.1f}s, loss {a['loss'][0]:.5f} -> {a['loss'][-1]:.5f}; host "
           f"free-running {host_iters} iterations in {t_host:.1f}s: max relative loss-curve distance {rel.max():.3e} "
@@ -166,6 +171,7 @@ def test_c4_at_size_parity_and_densify_loop(hip_device):
             gm = ref_loop.model_from_cloud(R, cloud, dev)
             opt = R.arguments.GSParams()
             opt.percent_dense = 0.0035 / 3.0            # clone/split boundary at the cloud's median scale (extent 3)
+            opt.lambda_dssim = 0.0                      # L1 only: the two runs must be bit-repeatable (see ref_loop.train)
             hist = []
 
             def densify(it, gm_, pkg, loss):
