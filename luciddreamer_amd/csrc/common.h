@@ -83,8 +83,10 @@ constexpr int PART_BINS_MAX = 16384;        // partition bins: one 4-byte LDS co
 constexpr int PART_BLOCKS_MAX = 256;        // workgroups of the count / scatter kernels (rows of the histogram)
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MIN_GAUSS = 1024;        // emitting Gaussians per workgroup before another workgroup is used
-constexpr int TSORT_THREADS = 256;
-constexpr int TSORT_LDS = 2048;             // bin entries the per-bin sort keeps in LDS (16 KB)
+constexpr int TSORT_LDS = 256;              // bin entries sorted by one wave (2 KB of LDS)
+constexpr int TSORT_THREADS = 256;          // threads of the middle class
+constexpr int TSORT_MID_LDS = 4096;         // ... its bin entries (32 KB)
+constexpr int TSORT_MID_BLOCKS = 1024;
 constexpr int TSORT_BIG_LDS = 16384;        // ... the large-bin kernel (128 KB); beyond: in place in global memory
 constexpr int TSORT_BIG_BLOCKS = 64;
 struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)

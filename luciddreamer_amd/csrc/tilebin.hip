@@ -17,18 +17,20 @@
 //                                        exact tile test of every rectangle tile and histogram the hits over the
 //                                        partition bins in LDS (one bin per tile up to 16384 tiles; 2^s neighbouring
 //                                        tiles per bin beyond that).  Integer LDS atomics: counts are order-free.
-//   k_part_scan1 / k_part_scan2          per-bin prefix over the workgroups, prefix over the bins -> bin start, and
-//                                        the per-tile ranges directly (no identifyTileRanges pass, no memset).
-//   k_part<SCATTER>                      the same walk again; every hit takes the next free position of its bin from
+//   k_part_scan1                         per-bin prefix over the workgroups (+ bin totals).
+//   k_part<SCATTER>                      every workgroup first scans the bin totals itself (bin start; workgroup 0 also
+//                                        publishes the per-tile ranges: no identifyTileRanges pass, no memset); then
+//                                        the same walk again; every hit takes the next free position of its bin from
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
-//   k_tile_sort / k_tile_sort_big        one workgroup per bin sorts its words in LDS (bitonic network; > 2048 entries:
-//                                        a second kernel with 128 KB of LDS, > 16384: in place in global memory).
+//   k_tile_sort / _mid / _big            one workgroup per bin sorts its words in LDS (bitonic network; three size
+//                                        classes: <= 256 entries by one wave, <= 4096, <= 16384 with 128 KB of LDS;
+//                                        beyond that in place in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
 //                                        repeatable, whatever order the scatter produced.
 //
-// 9 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
+// 8 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
 // atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
 #include "common.h"
 
@@ -234,6 +236,71 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
     }
 }
 
+// Exclusive prefix over the bins, evaluated by every scatter workgroup for itself (1024 threads x up to 16 consecutive
+// bins: one block-wide scan) into its LDS cursor array; workgroup 0 also publishes bin_start and the per-tile ranges
+// (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
+// builds the queue of bins that are too large for the one-wave sort.
+__device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total,
+                                                  const uint32_t* __restrict__ row, uint32_t* s_bin, bool publish,
+                                                  uint32_t* __restrict__ bin_start, uint2* __restrict__ ranges,
+                                                  uint32_t* __restrict__ big_queue)
+{
+    constexpr int PER = PART_BINS_MAX / PART_THREADS;     // 16 consecutive bins per thread
+    __shared__ uint32_t s_wave[PART_THREADS / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int base = threadIdx.x * PER;
+    uint32_t v[PER];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < PER; i++) { v[i] = (base + i < bins) ? bin_total[base + i] : 0u; sum += v[i]; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int j = 0; j < w; j++) run += s_wave[j];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int bin = base + i;
+        if (bin < bins) {
+            s_bin[bin] = run + row[bin];
+            if (publish) {
+                bin_start[bin] = run;
+                if (sub_shift == 0) ranges[bin] = v[i] ? make_uint2(run, run + v[i]) : make_uint2(0u, 0u);   // empty: (0,0), :311
+            }
+        }
+        run += v[i];
+    }
+    if (publish) {
+        // the queue of bins too large for the one-wave sort, in bin order, by a second block scan (no atomics: returning
+        // global atomics on one word cost ~45 ns each on this part, and a dense 512^2 view queues every tile)
+        uint32_t nbig = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) nbig += v[i] > (uint32_t)TSORT_LDS ? 1u : 0u;
+        uint32_t binc = nbig;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(binc, off);
+            if (lane >= off) binc += t;
+        }
+        __syncthreads();                                  // s_wave is reused
+        if (lane == 63) s_wave[w] = binc;
+        __syncthreads();
+        uint32_t q = binc - nbig;
+        for (int j = 0; j < w; j++) q += s_wave[j];
+#pragma unroll
+        for (int i = 0; i < PER; i++)
+            if (v[i] > (uint32_t)TSORT_LDS) big_queue[1 + q++] = (uint32_t)(base + i);
+        if (threadIdx.x == PART_THREADS - 1) big_queue[0] = q;
+        if (sub_shift != 0)
+            for (int t = threadIdx.x; t < num_tiles; t += PART_THREADS) ranges[t] = make_uint2(0u, 0u);
+    }
+}
+
 // MODE 0: count (per-workgroup bin histogram -> part_hist[b][bin]; also records inst_gid[slot])
 // MODE 1: scatter (64-bit words into their bins)
 template <int MODE>
@@ -241,7 +308,8 @@ __global__ void __launch_bounds__(PART_THREADS)
 k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* __restrict__ vis_list,
        const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
        const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
-       uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_start, uint32_t* __restrict__ inst_gid,
+       uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
+       uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ inst_gid,
        unsigned long long* __restrict__ words)
 {
     extern __shared__ uint32_t s_bin[];                  // [bins]
@@ -254,7 +322,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     if (MODE == 0) {
         for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[i] = 0u;
     } else {
-        for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[i] = row[i] + bin_start[i];
+        bin_prefix_to_lds(bins, gx * gy, sub_shift, bin_total, row, s_bin, b == 0, bin_start, ranges, big_queue);
     }
     __syncthreads();
     uint32_t beg, end;
@@ -279,7 +347,8 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     }
 }
 
-// per bin: exclusive prefix over the active workgroups (in place), total -> bin_total
+// per bin: exclusive prefix over the active workgroups (in place), total -> bin_total.  Eight independent loads are in
+// flight per thread before the dependent adds / stores (a load-store-load chain over 90 rows cost 27 us, this ~3 us).
 __global__ void __launch_bounds__(256)
 k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict__ part_hist, uint32_t* __restrict__ bin_total)
 {
@@ -287,50 +356,17 @@ k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict_
     if (bin >= bins) return;
     const int nb = part_active_blocks(hdr->num_compact);
     uint32_t run = 0;
-    for (int b = 0; b < nb; b++) {
-        uint32_t* p = part_hist + (size_t)b * bins + bin;
-        const uint32_t v = *p;
-        *p = run;
-        run += v;
+    for (int b0 = 0; b0 < nb; b0 += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = (b0 + i < nb) ? part_hist[(size_t)(b0 + i) * bins + bin] : 0u;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (b0 + i < nb) part_hist[(size_t)(b0 + i) * bins + bin] = run;
+            run += v[i];
+        }
     }
     bin_total[bin] = run;
-}
-
-// one workgroup: exclusive prefix over the bins -> bin_start; per-tile ranges when a bin is a tile (sub_shift == 0),
-// zeroed ranges otherwise (k_tile_sort fills them in); resets the queue of large bins
-__global__ void __launch_bounds__(1024)
-k_part_scan2(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
-             uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue)
-{
-    __shared__ uint32_t s_wave[16];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) { s_carry = 0; big_queue[0] = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < bins; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = (i < bins) ? bin_total[i] : 0u;
-        uint32_t inc = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(inc, off);
-            if (lane >= off) inc += t;
-        }
-        if (lane == 63) s_wave[w] = inc;
-        __syncthreads();
-        uint32_t wb = s_carry;
-        for (int j = 0; j < w; j++) wb += s_wave[j];
-        const uint32_t start = wb + inc - v;
-        if (i < bins) {
-            bin_start[i] = start;
-            if (sub_shift == 0) ranges[i] = v ? make_uint2(start, start + v) : make_uint2(0u, 0u);   // empty: (0,0), :311
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = start + v;
-        __syncthreads();
-    }
-    if (sub_shift != 0)
-        for (int t = threadIdx.x; t < num_tiles; t += 1024) ranges[t] = make_uint2(0u, 0u);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -379,24 +415,44 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
     }
 }
 
-__global__ void __launch_bounds__(TSORT_THREADS)
+// Three size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
+// resident at once; a C3 tile holds ~50 entries); larger bins are queued.  k_tile_sort_mid: 256 threads, up to 4096
+// entries (32 KB).  k_tile_sort_big: 1024 threads, up to 16384 entries in 128 KB of LDS, beyond that in place in
+// global memory.  The two queue kernels are always launched and return at once when the queue holds nothing for them.
+__global__ void __launch_bounds__(64)
 k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
             const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
-            uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue)
+            uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
     __shared__ unsigned long long s_a[TSORT_LDS];
     const int bin = (int)blockIdx.x;
     const uint32_t n = bin_total[bin];
     if (n == 0) return;
-    if (n > (uint32_t)TSORT_LDS) {                       // rare: handed to k_tile_sort_big
-        if (threadIdx.x == 0) big_queue[1 + atomicAdd(&big_queue[0], 1u)] = (uint32_t)bin;
-        return;
-    }
+    if (n > (uint32_t)TSORT_LDS) return;               // queued for k_tile_sort_mid / _big by the scatter kernel
     const uint32_t start = bin_start[bin];
-    for (uint32_t i = threadIdx.x; i < n; i += TSORT_THREADS) s_a[i] = words[start + i];
+    for (uint32_t i = threadIdx.x; i < n; i += 64) s_a[i] = words[start + i];
     __syncthreads();
-    if (n > 1) bitonic_sort(s_a, n, threadIdx.x, TSORT_THREADS, [] { __syncthreads(); });
-    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, TSORT_THREADS, point_list, ranges);
+    if (n > 1) bitonic_sort(s_a, n, threadIdx.x, 64u, [] { __syncthreads(); });
+    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 64u, point_list, ranges);
+}
+
+__global__ void __launch_bounds__(TSORT_THREADS)
+k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+                const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
+                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue)
+{
+    __shared__ unsigned long long s_a[TSORT_MID_LDS];
+    const uint32_t count = big_queue[0];
+    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
+        const int bin = (int)big_queue[1 + q];
+        const uint32_t n = bin_total[bin], start = bin_start[bin];
+        if (n > (uint32_t)TSORT_MID_LDS) continue;           // k_tile_sort_big's
+        for (uint32_t i = threadIdx.x; i < n; i += TSORT_THREADS) s_a[i] = words[start + i];
+        __syncthreads();
+        bitonic_sort(s_a, n, threadIdx.x, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+        write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, (uint32_t)TSORT_THREADS, point_list, ranges);
+        __syncthreads();
+    }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -409,18 +465,19 @@ k_tile_sort_big(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
     for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
         const int bin = (int)big_queue[1 + q];
         const uint32_t n = bin_total[bin], start = bin_start[bin];
+        if (n <= (uint32_t)TSORT_MID_LDS) continue;          // k_tile_sort_mid's
         if (n <= (uint32_t)TSORT_BIG_LDS) {
             for (uint32_t i = threadIdx.x; i < n; i += 1024) s_big[i] = words[start + i];
             __syncthreads();
-            bitonic_sort(s_big, n, threadIdx.x, 1024, [] { __syncthreads(); });
-            write_sorted(s_big, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024, point_list, ranges);
+            bitonic_sort(s_big, n, threadIdx.x, 1024u, [] { __syncthreads(); });
+            write_sorted(s_big, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024u, point_list, ranges);
         } else {
             // larger than the LDS: the same network in place in global memory (one workgroup, L2-resident; slow, but a
             // single tile with more than 16384 splats is slow to blend anyway)
             unsigned long long* a = words + start;
             __syncthreads();
-            bitonic_sort(a, n, threadIdx.x, 1024, [] { __threadfence(); __syncthreads(); });
-            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024, point_list, ranges);
+            bitonic_sort(a, n, threadIdx.x, 1024u, [] { __threadfence(); __syncthreads(); });
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024u, point_list, ranges);
         }
         __syncthreads();
     }
@@ -474,16 +531,18 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     const size_t lds = (size_t)pp.bins * 4;
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
-                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_start, inst_gid, words);
+                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
+                       inst_gid, words);
     if (t) t->mark(1, s);
     hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + 255) / 256), dim3(256), 0, s, pp.bins, hdr, part_hist, bin_total);
-    hipLaunchKernelGGL(k_part_scan2, dim3(1), dim3(1024), 0, s, pp.bins, num_tiles, pp.sub_shift, bin_total, bin_start, ranges,
-                       big_queue);
     if (t) t->mark(2, s);
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
-                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_start, inst_gid, words);
+                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
+                       inst_gid, words);
     if (t) t->mark(3, s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(TSORT_THREADS), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
+    hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(64), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
+                       bin_start, bin_total, words, point_list, ranges);
+    hipLaunchKernelGGL(k_tile_sort_mid, dim3(TSORT_MID_BLOCKS), dim3(TSORT_THREADS), 0, s, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges, big_queue);
     hipLaunchKernelGGL(k_tile_sort_big, dim3(TSORT_BIG_BLOCKS), dim3(1024), (size_t)TSORT_BIG_LDS * 8, s, pp.sub_shift, slot_bits,
                        num_tiles, bin_start, bin_total, words, point_list, ranges, big_queue);
