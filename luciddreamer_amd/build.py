@@ -83,6 +83,41 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
+
+
+def ext_path():
+    import sysconfig
+    return os.path.join(_HERE, "_C_ext" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_ext(force=False, verbose=False):
+    """In-tree build of luciddreamer_amd/_C_ext*.so: the compiled torch binding over the C-ABI (csrc/torch_ext.cpp;
+    host code only, g++ against the torch / HIP headers, linked to lib/liblucid_raster.so with an $ORIGIN rpath)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    out = ext_path()
+    deps = [EXT_SRC, os.path.join(INCLUDE, "lucid_raster.h"), os.path.abspath(__file__)]
+    if not force and not _stale(out, deps):
+        return out
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", EXT_SRC, "-o", out,
+           "-DTORCH_EXTENSION_NAME=_C_ext", "-DTORCH_API_INCLUDE_EXTENSION_H", "-DUSE_ROCM", "-D__HIP_PLATFORM_AMD__",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-I", INCLUDE, "-I", os.path.join(rocm, "include"),
+           "-I", sysconfig.get_paths()["include"]]
+    for inc in ce.include_paths():
+        cmd += ["-isystem", inc]
+    torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd += ["-L", torch_lib, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+            "-L", LIBDIR, "-llucid_raster", "-Wl,-rpath,$ORIGIN/lib", f"-Wl,-rpath,{torch_lib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)
+    print(build_ext(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -1,0 +1,321 @@
+// torch_ext.cpp -- compiled binding `luciddreamer_amd._C_ext` between torch tensors and the C-ABI of liblucid_raster.so
+// (include/lucid_raster.h).  Takes the place of the reference's pybind11 layer RAST/rasterize_points.cu:35-221 (tensor
+// checks, output / gradient allocation, resizable scratch tensors handed to the rasterizer through allocator
+// callbacks, pointer marshalling) for the per-view entry points:
+//
+//     rasterize_gaussians            RAST/rasterize_points.h:18-38
+//     rasterize_gaussians_backward   RAST/rasterize_points.h:40-63
+//     mark_visible                   RAST/rasterize_points.h:65-68
+//     (+ the raw-parameter pair and check(), which have no reference counterpart)
+//
+// No device code here: torch is used for device memory and the current HIP stream only.  Round 1 did this in
+// Python over ctypes (0.35 ms of host time per view against 0.25 ms of GPU time); here a forward costs three
+// at::empty calls for the scratch tensors, three for the outputs and one C call.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+#include <c10/hip/HIPGuard.h>
+
+#include <string>
+#include <vector>
+
+#include "lucid_raster.h"
+
+namespace {
+
+using OptT = c10::optional<at::Tensor>;
+
+void require_device(const at::Tensor& t, const char* name)
+{
+    TORCH_CHECK(t.is_cuda(), "luciddreamer_amd: ", name, " must be on a HIP device (got ", t.device(),
+                "); this rasterizer has no CPU path (neither has the reference: RAST/rasterize_points.cu:72)");
+}
+
+// float32, contiguous, on `dev`; empty tensors (the reference's `torch.Tensor([])` placeholders,
+// RAST/.../__init__.py:198-208) and None become "absent"
+struct Arg {
+    at::Tensor t;
+    const float* p = nullptr;
+};
+Arg f32(const OptT& o, const c10::Device& dev, const char* name)
+{
+    Arg a;
+    if (!o.has_value() || !o->defined() || o->numel() == 0) return a;
+    TORCH_CHECK(o->scalar_type() == at::kFloat, name, " must be float32 (got ", o->scalar_type(), ")");
+    a.t = *o;
+    if (a.t.device() != dev) a.t = a.t.to(dev);
+    if (!a.t.is_contiguous()) a.t = a.t.contiguous();
+    a.p = a.t.data_ptr<float>();
+    return a;
+}
+
+struct Scratch {
+    at::Tensor t;
+    c10::Device dev;
+    explicit Scratch(c10::Device d) : dev(d) {}
+};
+char* scratch_alloc(size_t bytes, void* user)
+{
+    Scratch* s = static_cast<Scratch*>(user);
+    s->t = at::empty({static_cast<int64_t>(bytes > 0 ? bytes : 1)}, at::TensorOptions().dtype(at::kByte).device(s->dev));
+    return static_cast<char*>(s->t.data_ptr());
+}
+
+[[noreturn]] void raise_for(int rc, const char* what)
+{
+    const std::string msg = lr_last_error();
+    // the reference raises std::runtime_error for all of these (rasterizer_impl.cu:243-246, auxiliary.h:166-173)
+    TORCH_CHECK(false, msg.empty() ? std::string(what) + " failed with code " + std::to_string(rc) : msg);
+}
+
+int sh_coeffs(const OptT& sh)        // rasterize_points.cu:84-88
+{
+    return (sh.has_value() && sh->defined() && sh->numel() != 0 && sh->size(0) != 0) ? static_cast<int>(sh->size(1)) : 0;
+}
+
+using FwdResult = std::tuple<int64_t, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor, at::Tensor>;
+
+FwdResult empty_forward(const c10::Device& dev, int64_t H, int64_t W)
+{
+    // rasterize_points.cu:68-82: zero images, empty scratch, nothing launched
+    auto f = at::TensorOptions().dtype(at::kFloat).device(dev);
+    auto b = at::TensorOptions().dtype(at::kByte).device(dev);
+    return FwdResult(0, at::zeros({3, H, W}, f), at::zeros({1, H, W}, f), at::empty({0}, f.dtype(at::kInt)),
+                     at::empty({0}, b), at::empty({0}, b), at::empty({0}, b));
+}
+
+FwdResult rasterize_gaussians(const at::Tensor& background, const at::Tensor& means3D, const OptT& colors, const at::Tensor& opacity,
+                              const OptT& scales, const OptT& rotations, double scale_modifier, const OptT& cov3D_precomp,
+                              const at::Tensor& viewmatrix, const at::Tensor& projmatrix, double tan_fovx, double tan_fovy,
+                              int64_t image_height, int64_t image_width, const OptT& sh, int64_t degree, const at::Tensor& campos,
+                              bool prefiltered, bool debug, int64_t binning_capacity)
+{
+    TORCH_CHECK(means3D.dim() == 2 && means3D.size(1) == 3, "means3D must have dimensions (num_points, 3)");   // :57-59
+    require_device(means3D, "means3D");
+    const c10::Device dev = means3D.device();
+    const int64_t P = means3D.size(0), H = image_height, W = image_width;
+    if (P == 0) return empty_forward(dev, H, W);
+    c10::hip::HIPGuard guard(dev);
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    at::Tensor out_color = at::empty({3, H, W}, fopt);          // fully written by the library: no zero fill (:68-70)
+    at::Tensor out_depth = at::empty({1, H, W}, fopt);
+    at::Tensor radii = at::empty({P}, fopt.dtype(at::kInt));
+    const Arg m = f32(means3D, dev, "means3D"), bg = f32(background, dev, "background"), col = f32(colors, dev, "colors_precomp"),
+              op = f32(opacity, dev, "opacities"), sc = f32(scales, dev, "scales"), rot = f32(rotations, dev, "rotations"),
+              cov = f32(cov3D_precomp, dev, "cov3D_precomp"), view = f32(viewmatrix, dev, "viewmatrix"),
+              proj = f32(projmatrix, dev, "projmatrix"), cam = f32(campos, dev, "campos"), shc = f32(sh, dev, "sh");
+    Scratch geom(dev), binning(dev), img(dev);
+    const int rc = lr_forward(scratch_alloc, &geom, scratch_alloc, &binning, scratch_alloc, &img, static_cast<int>(P),
+                              static_cast<int>(degree), sh_coeffs(sh), bg.p, static_cast<int>(W), static_cast<int>(H), m.p, shc.p,
+                              col.p, op.p, sc.p, static_cast<float>(scale_modifier), rot.p, cov.p, view.p, proj.p, cam.p,
+                              static_cast<float>(tan_fovx), static_cast<float>(tan_fovy), prefiltered ? 1 : 0,
+                              out_color.data_ptr<float>(), out_depth.data_ptr<float>(), radii.data_ptr<int>(), debug ? 1 : 0,
+                              static_cast<long long>(binning_capacity), c10::hip::getCurrentHIPStream(dev.index()).stream());
+    if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) raise_for(rc, "rasterize_gaussians");
+    if (!binning.t.defined()) binning.t = at::empty({0}, at::TensorOptions().dtype(at::kByte).device(dev));
+    return FwdResult(rc, out_color, out_depth, radii, geom.t, binning.t, img.t);
+}
+
+// accumulate: eight optional tensors in the order of the returned tuple (means2D, colors, opacity, means3D, cov3D, sh,
+// scales, rotations); a given tensor receives `+=` in place (rows of culled Gaussians untouched) and its slot of the
+// result is None.  skip_unused: gradients of absent input representations are not materialised (None).
+std::vector<OptT> rasterize_gaussians_backward(
+    const at::Tensor& background, const at::Tensor& means3D, const at::Tensor& radii, const OptT& colors, const OptT& scales,
+    const OptT& rotations, double scale_modifier, const OptT& cov3D_precomp, const at::Tensor& viewmatrix,
+    const at::Tensor& projmatrix, double tan_fovx, double tan_fovy, const at::Tensor& dL_dout_color, const OptT& dL_dout_depth,
+    const OptT& sh, int64_t degree, const at::Tensor& campos, const at::Tensor& geomBuffer, int64_t R,
+    const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug, int64_t binning_capacity,
+    const std::vector<OptT>& accumulate, bool skip_unused)
+{
+    require_device(means3D, "means3D");
+    const c10::Device dev = means3D.device();
+    const int64_t P = means3D.size(0);
+    const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+    const int M = sh_coeffs(sh);
+    TORCH_CHECK(accumulate.empty() || accumulate.size() == 8, "accumulate: eight entries or none");
+    c10::hip::HIPGuard guard(dev);
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    // order of the result tuple (rasterize_points.cu:199) and the LR_ACC_* bit of each entry
+    static const int kBit[8] = { 0, 3, 2, 4, 5, 6, 7, 8 };
+    const std::vector<int64_t> shapes[8] = { { P, 3 }, { P, 3 }, { P, 1 }, { P, 3 }, { P, 6 }, { P, M, 3 }, { P, 3 }, { P, 4 } };
+    const Arg col = f32(colors, dev, "colors_precomp"), sc = f32(scales, dev, "scales"), rot = f32(rotations, dev, "rotations"),
+              cov = f32(cov3D_precomp, dev, "cov3D_precomp");
+    const bool unused[8] = { false, skip_unused && !col.p, false, false, skip_unused && !cov.p, false, skip_unused && !sc.p,
+                             skip_unused && !sc.p };
+    at::Tensor out[8];
+    float* ptr[8];
+    unsigned int mask = 0;
+    std::vector<OptT> result(8);
+    for (int k = 0; k < 8; k++) {
+        ptr[k] = nullptr;
+        if (unused[k]) continue;
+        if (!accumulate.empty() && accumulate[k].has_value() && accumulate[k]->defined()) {
+            const at::Tensor& t = *accumulate[k];
+            int64_t n = 1;
+            for (int64_t d : shapes[k]) n *= d;
+            TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous() && t.device() == dev && t.numel() == n,
+                        "accumulate tensors must be contiguous float32 of the gradient's size on ", dev);
+            mask |= 1u << kBit[k];
+            out[k] = t;
+        } else {
+            out[k] = at::empty(shapes[k], fopt);     // fully written by the library (culled rows = 0), cf. :154-162
+            result[k] = out[k];
+        }
+        ptr[k] = out[k].numel() ? out[k].data_ptr<float>() : nullptr;
+    }
+    if (P != 0) {
+        const Arg m = f32(means3D, dev, "means3D"), bg = f32(background, dev, "background"), view = f32(viewmatrix, dev, "viewmatrix"),
+                  proj = f32(projmatrix, dev, "projmatrix"), cam = f32(campos, dev, "campos"), shc = f32(sh, dev, "sh"),
+                  gc = f32(dL_dout_color, dev, "dL_dout_color"), gd = f32(dL_dout_depth, dev, "dL_dout_depth");
+        const at::Tensor radii_c = radii.contiguous();
+        const int rc = lr_backward(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
+                                   static_cast<int>(H), m.p, shc.p, col.p, sc.p, static_cast<float>(scale_modifier), rot.p, cov.p,
+                                   view.p, proj.p, cam.p, static_cast<float>(tan_fovx), static_cast<float>(tan_fovy),
+                                   radii_c.data_ptr<int>(), static_cast<char*>(geomBuffer.data_ptr()),
+                                   static_cast<char*>(binningBuffer.data_ptr()), static_cast<char*>(imageBuffer.data_ptr()), gc.p, gd.p,
+                                   ptr[0], nullptr, ptr[2], ptr[1], ptr[3], ptr[4], M ? ptr[5] : nullptr, ptr[6], ptr[7],
+                                   debug ? 1 : 0, static_cast<long long>(binning_capacity), mask,
+                                   c10::hip::getCurrentHIPStream(dev.index()).stream());
+        if (rc < 0) raise_for(rc, "rasterize_gaussians_backward");
+    }
+    return result;
+}
+
+FwdResult rasterize_gaussians_raw(const at::Tensor& background, const at::Tensor& xyz, const at::Tensor& features_dc,
+                                  const OptT& features_rest, const at::Tensor& opacity_raw, const at::Tensor& scaling_raw,
+                                  const at::Tensor& rotation_raw, double scale_modifier, const at::Tensor& viewmatrix,
+                                  const at::Tensor& projmatrix, double tan_fovx, double tan_fovy, int64_t image_height,
+                                  int64_t image_width, int64_t degree, const at::Tensor& campos, bool debug,
+                                  int64_t binning_capacity)
+{
+    TORCH_CHECK(xyz.dim() == 2 && xyz.size(1) == 3, "means3D must have dimensions (num_points, 3)");
+    require_device(xyz, "xyz");
+    const c10::Device dev = xyz.device();
+    const int64_t P = xyz.size(0), H = image_height, W = image_width;
+    if (P == 0) return empty_forward(dev, H, W);
+    TORCH_CHECK(features_dc.numel() == 3 * P, "features_dc must have dimensions (num_points, 1, 3)");
+    c10::hip::HIPGuard guard(dev);
+    const Arg rest = f32(features_rest, dev, "features_rest");
+    const int M = 1 + (rest.p ? static_cast<int>(features_rest->size(1)) : 0);
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    at::Tensor out_color = at::empty({3, H, W}, fopt), out_depth = at::empty({1, H, W}, fopt);
+    at::Tensor radii = at::empty({P}, fopt.dtype(at::kInt));
+    const Arg bg = f32(background, dev, "background"), x = f32(xyz, dev, "xyz"), dc = f32(features_dc, dev, "features_dc"),
+              op = f32(opacity_raw, dev, "opacity"), sc = f32(scaling_raw, dev, "scaling"), rot = f32(rotation_raw, dev, "rotation"),
+              view = f32(viewmatrix, dev, "viewmatrix"), proj = f32(projmatrix, dev, "projmatrix"), cam = f32(campos, dev, "campos");
+    Scratch geom(dev), binning(dev), img(dev);
+    const int rc = lr_forward_raw(scratch_alloc, &geom, scratch_alloc, &binning, scratch_alloc, &img, static_cast<int>(P),
+                                  static_cast<int>(degree), M, bg.p, static_cast<int>(W), static_cast<int>(H), x.p, dc.p, rest.p, op.p,
+                                  sc.p, static_cast<float>(scale_modifier), rot.p, view.p, proj.p, cam.p, static_cast<float>(tan_fovx),
+                                  static_cast<float>(tan_fovy), out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
+                                  radii.data_ptr<int>(), debug ? 1 : 0, static_cast<long long>(binning_capacity),
+                                  c10::hip::getCurrentHIPStream(dev.index()).stream());
+    if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) raise_for(rc, "rasterize_gaussians_raw");
+    if (!binning.t.defined()) binning.t = at::empty({0}, at::TensorOptions().dtype(at::kByte).device(dev));
+    return FwdResult(rc, out_color, out_depth, radii, geom.t, binning.t, img.t);
+}
+
+// result / accumulate order: (means2D, xyz, features_dc, features_rest, opacity, scaling, rotation)
+std::vector<OptT> rasterize_gaussians_raw_backward(
+    const at::Tensor& background, const at::Tensor& xyz, const at::Tensor& radii, const at::Tensor& features_dc,
+    const OptT& features_rest, const at::Tensor& opacity_raw, const at::Tensor& scaling_raw, const at::Tensor& rotation_raw,
+    double scale_modifier, const at::Tensor& viewmatrix, const at::Tensor& projmatrix, double tan_fovx, double tan_fovy,
+    const at::Tensor& dL_dout_color, int64_t degree, const at::Tensor& campos, const at::Tensor& geomBuffer, int64_t R,
+    const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug, int64_t binning_capacity,
+    const std::vector<OptT>& accumulate)
+{
+    require_device(xyz, "xyz");
+    const c10::Device dev = xyz.device();
+    const int64_t P = xyz.size(0);
+    const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+    c10::hip::HIPGuard guard(dev);
+    const Arg rest = f32(features_rest, dev, "features_rest");
+    const int64_t nrest = rest.p ? features_rest->size(1) : 0;
+    const int M = 1 + static_cast<int>(nrest);
+    TORCH_CHECK(accumulate.empty() || accumulate.size() == 7, "accumulate: seven entries or none");
+    auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
+    static const int kBit[7] = { 0, 4, 6, 6, 2, 7, 8 };                 // features_dc and features_rest share LR_ACC_SH
+    const std::vector<int64_t> shapes[7] = { { P, 3 }, { P, 3 }, { P, 1, 3 }, { P, nrest, 3 }, { P, 1 }, { P, 3 }, { P, 4 } };
+    const bool have_acc = !accumulate.empty();
+    const bool feat_acc = have_acc && accumulate[2].has_value() && accumulate[2]->defined() &&
+                          (nrest == 0 || (accumulate[3].has_value() && accumulate[3]->defined()));
+    at::Tensor out[7];
+    float* ptr[7];
+    unsigned int mask = 0;
+    std::vector<OptT> result(7);
+    for (int k = 0; k < 7; k++) {
+        const bool is_feat = (k == 2 || k == 3);
+        const bool acc = have_acc && (is_feat ? feat_acc : (accumulate[k].has_value() && accumulate[k]->defined())) &&
+                         !(k == 3 && nrest == 0);
+        if (acc) {
+            const at::Tensor& t = *accumulate[k];
+            int64_t n = 1;
+            for (int64_t d : shapes[k]) n *= d;
+            TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous() && t.device() == dev && t.numel() == n,
+                        "accumulate tensors must be contiguous float32 of the gradient's size on ", dev);
+            mask |= 1u << kBit[k];
+            out[k] = t;
+        } else {
+            out[k] = at::empty(shapes[k], fopt);
+            if (!(is_feat && feat_acc)) result[k] = out[k];
+        }
+        ptr[k] = out[k].numel() ? out[k].data_ptr<float>() : nullptr;
+    }
+    if (P != 0) {
+        const Arg bg = f32(background, dev, "background"), x = f32(xyz, dev, "xyz"), dc = f32(features_dc, dev, "features_dc"),
+                  op = f32(opacity_raw, dev, "opacity"), sc = f32(scaling_raw, dev, "scaling"), rot = f32(rotation_raw, dev, "rotation"),
+                  view = f32(viewmatrix, dev, "viewmatrix"), proj = f32(projmatrix, dev, "projmatrix"), cam = f32(campos, dev, "campos"),
+                  gc = f32(dL_dout_color, dev, "dL_dout_color");
+        const at::Tensor radii_c = radii.contiguous();
+        const int rc = lr_backward_raw(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
+                                       static_cast<int>(H), x.p, dc.p, rest.p, op.p, sc.p, static_cast<float>(scale_modifier), rot.p,
+                                       view.p, proj.p, cam.p, static_cast<float>(tan_fovx), static_cast<float>(tan_fovy),
+                                       radii_c.data_ptr<int>(), static_cast<char*>(geomBuffer.data_ptr()),
+                                       static_cast<char*>(binningBuffer.data_ptr()), static_cast<char*>(imageBuffer.data_ptr()), gc.p,
+                                       ptr[0], ptr[4], ptr[1], ptr[2], nrest ? ptr[3] : nullptr, ptr[5], ptr[6], debug ? 1 : 0,
+                                       static_cast<long long>(binning_capacity), mask,
+                                       c10::hip::getCurrentHIPStream(dev.index()).stream());
+        if (rc < 0) raise_for(rc, "rasterize_gaussians_raw_backward");
+    }
+    return result;
+}
+
+at::Tensor mark_visible(const at::Tensor& means3D, const at::Tensor& viewmatrix, const at::Tensor& projmatrix)
+{
+    require_device(means3D, "means3D");
+    const c10::Device dev = means3D.device();
+    const int64_t P = means3D.size(0);
+    at::Tensor present = at::empty({P}, at::TensorOptions().dtype(at::kBool).device(dev));
+    if (P != 0) {
+        c10::hip::HIPGuard guard(dev);
+        const Arg m = f32(means3D, dev, "means3D"), v = f32(viewmatrix, dev, "viewmatrix"), p = f32(projmatrix, dev, "projmatrix");
+        const int rc = lr_mark_visible(static_cast<int>(P), m.p, v.p, p.p, static_cast<unsigned char*>(present.data_ptr()),
+                                       c10::hip::getCurrentHIPStream(dev.index()).stream());
+        if (rc < 0) raise_for(rc, "mark_visible");
+    }
+    return present;
+}
+
+// synchronise and return num_rendered of a forward; raises on async-mode overflow / prefiltered trap
+int64_t check(const at::Tensor& geomBuffer)
+{
+    c10::hip::HIPGuard guard(geomBuffer.device());
+    long long n = 0;
+    const int rc = lr_check(static_cast<const char*>(geomBuffer.data_ptr()), &n,
+                            c10::hip::getCurrentHIPStream(geomBuffer.device().index()).stream());
+    if (rc < 0) raise_for(rc, "check");
+    return n;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "luciddreamer_amd: torch <-> liblucid_raster.so (C-ABI) binding of the per-view rasterizer entry points";
+    m.def("rasterize_gaussians", &rasterize_gaussians);
+    m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
+    m.def("rasterize_gaussians_raw", &rasterize_gaussians_raw);
+    m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
+    m.def("mark_visible", &mark_visible);
+    m.def("check", &check);
+    m.def("version", [] { return std::string(lr_version()); });
+}

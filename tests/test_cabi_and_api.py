@@ -104,6 +104,18 @@ def test_cpu_tensors_are_rejected_not_silently_computed():
         distCUDA2(m)
 
 
+def test_compiled_binding_is_the_one_in_tree():
+    """The per-view entry points go through the compiled module luciddreamer_amd/_C_ext*.so (csrc/torch_ext.cpp), which
+    links the in-tree C-ABI library; luciddreamer_amd._C is only its keyword adapter."""
+    from luciddreamer_amd import _C, _C_ext, _lib
+    assert os.path.dirname(os.path.abspath(_C_ext.__file__)) == os.path.join(ROOT, "luciddreamer_amd")
+    assert _C_ext.version() == _lib.lib().lr_version().decode()
+    assert _C.mark_visible is _C_ext.mark_visible and _C.check is _C_ext.check
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "rasterize_gaussians_raw",
+                 "rasterize_gaussians_raw_backward"):
+        assert callable(getattr(_C_ext, name)) and callable(getattr(_C, name))
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from luciddreamer_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
