@@ -12,8 +12,10 @@
 // Python over ctypes (0.35 ms of host time per view against 0.25 ms of GPU time); here a forward costs three
 // at::empty calls for the scratch tensors, three for the outputs and one C call.
 #include <torch/extension.h>
-#include <c10/hip/HIPStream.h>
-#include <c10/hip/HIPGuard.h>
+// ROCm builds of torch present HIP devices under the device type "cuda": the guard / stream classes to use are the
+// "MasqueradingAsCUDA" ones (the plain c10::hip guard rejects a "cuda" device)
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <string>
 #include <vector>
@@ -94,7 +96,7 @@ FwdResult rasterize_gaussians(const at::Tensor& background, const at::Tensor& me
     const c10::Device dev = means3D.device();
     const int64_t P = means3D.size(0), H = image_height, W = image_width;
     if (P == 0) return empty_forward(dev, H, W);
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     at::Tensor out_color = at::empty({3, H, W}, fopt);          // fully written by the library: no zero fill (:68-70)
     at::Tensor out_depth = at::empty({1, H, W}, fopt);
@@ -109,7 +111,7 @@ FwdResult rasterize_gaussians(const at::Tensor& background, const at::Tensor& me
                               col.p, op.p, sc.p, static_cast<float>(scale_modifier), rot.p, cov.p, view.p, proj.p, cam.p,
                               static_cast<float>(tan_fovx), static_cast<float>(tan_fovy), prefiltered ? 1 : 0,
                               out_color.data_ptr<float>(), out_depth.data_ptr<float>(), radii.data_ptr<int>(), debug ? 1 : 0,
-                              static_cast<long long>(binning_capacity), c10::hip::getCurrentHIPStream(dev.index()).stream());
+                              static_cast<long long>(binning_capacity), c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
     if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) raise_for(rc, "rasterize_gaussians");
     if (!binning.t.defined()) binning.t = at::empty({0}, at::TensorOptions().dtype(at::kByte).device(dev));
     return FwdResult(rc, out_color, out_depth, radii, geom.t, binning.t, img.t);
@@ -132,7 +134,7 @@ std::vector<OptT> rasterize_gaussians_backward(
     const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
     const int M = sh_coeffs(sh);
     TORCH_CHECK(accumulate.empty() || accumulate.size() == 8, "accumulate: eight entries or none");
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
     // order of the result tuple (rasterize_points.cu:199) and the LR_ACC_* bit of each entry
     static const int kBit[8] = { 0, 3, 2, 4, 5, 6, 7, 8 };
@@ -174,7 +176,7 @@ std::vector<OptT> rasterize_gaussians_backward(
                                    static_cast<char*>(binningBuffer.data_ptr()), static_cast<char*>(imageBuffer.data_ptr()), gc.p, gd.p,
                                    ptr[0], nullptr, ptr[2], ptr[1], ptr[3], ptr[4], M ? ptr[5] : nullptr, ptr[6], ptr[7],
                                    debug ? 1 : 0, static_cast<long long>(binning_capacity), mask,
-                                   c10::hip::getCurrentHIPStream(dev.index()).stream());
+                                   c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
         if (rc < 0) raise_for(rc, "rasterize_gaussians_backward");
     }
     return result;
@@ -193,7 +195,7 @@ FwdResult rasterize_gaussians_raw(const at::Tensor& background, const at::Tensor
     const int64_t P = xyz.size(0), H = image_height, W = image_width;
     if (P == 0) return empty_forward(dev, H, W);
     TORCH_CHECK(features_dc.numel() == 3 * P, "features_dc must have dimensions (num_points, 1, 3)");
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const Arg rest = f32(features_rest, dev, "features_rest");
     const int M = 1 + (rest.p ? static_cast<int>(features_rest->size(1)) : 0);
     auto fopt = at::TensorOptions().dtype(at::kFloat).device(dev);
@@ -208,7 +210,7 @@ FwdResult rasterize_gaussians_raw(const at::Tensor& background, const at::Tensor
                                   sc.p, static_cast<float>(scale_modifier), rot.p, view.p, proj.p, cam.p, static_cast<float>(tan_fovx),
                                   static_cast<float>(tan_fovy), out_color.data_ptr<float>(), out_depth.data_ptr<float>(),
                                   radii.data_ptr<int>(), debug ? 1 : 0, static_cast<long long>(binning_capacity),
-                                  c10::hip::getCurrentHIPStream(dev.index()).stream());
+                                  c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
     if (rc < 0 && rc != LR_NUM_RENDERED_ON_DEVICE) raise_for(rc, "rasterize_gaussians_raw");
     if (!binning.t.defined()) binning.t = at::empty({0}, at::TensorOptions().dtype(at::kByte).device(dev));
     return FwdResult(rc, out_color, out_depth, radii, geom.t, binning.t, img.t);
@@ -227,7 +229,7 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
     const c10::Device dev = xyz.device();
     const int64_t P = xyz.size(0);
     const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
-    c10::hip::HIPGuard guard(dev);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
     const Arg rest = f32(features_rest, dev, "features_rest");
     const int64_t nrest = rest.p ? features_rest->size(1) : 0;
     const int M = 1 + static_cast<int>(nrest);
@@ -273,7 +275,7 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
                                        static_cast<char*>(binningBuffer.data_ptr()), static_cast<char*>(imageBuffer.data_ptr()), gc.p,
                                        ptr[0], ptr[4], ptr[1], ptr[2], nrest ? ptr[3] : nullptr, ptr[5], ptr[6], debug ? 1 : 0,
                                        static_cast<long long>(binning_capacity), mask,
-                                       c10::hip::getCurrentHIPStream(dev.index()).stream());
+                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
         if (rc < 0) raise_for(rc, "rasterize_gaussians_raw_backward");
     }
     return result;
@@ -286,10 +288,10 @@ at::Tensor mark_visible(const at::Tensor& means3D, const at::Tensor& viewmatrix,
     const int64_t P = means3D.size(0);
     at::Tensor present = at::empty({P}, at::TensorOptions().dtype(at::kBool).device(dev));
     if (P != 0) {
-        c10::hip::HIPGuard guard(dev);
+        c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
         const Arg m = f32(means3D, dev, "means3D"), v = f32(viewmatrix, dev, "viewmatrix"), p = f32(projmatrix, dev, "projmatrix");
         const int rc = lr_mark_visible(static_cast<int>(P), m.p, v.p, p.p, static_cast<unsigned char*>(present.data_ptr()),
-                                       c10::hip::getCurrentHIPStream(dev.index()).stream());
+                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
         if (rc < 0) raise_for(rc, "mark_visible");
     }
     return present;
@@ -298,10 +300,10 @@ at::Tensor mark_visible(const at::Tensor& means3D, const at::Tensor& viewmatrix,
 // synchronise and return num_rendered of a forward; raises on async-mode overflow / prefiltered trap
 int64_t check(const at::Tensor& geomBuffer)
 {
-    c10::hip::HIPGuard guard(geomBuffer.device());
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(geomBuffer.device());
     long long n = 0;
     const int rc = lr_check(static_cast<const char*>(geomBuffer.data_ptr()), &n,
-                            c10::hip::getCurrentHIPStream(geomBuffer.device().index()).stream());
+                            c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(geomBuffer.device().index()).stream());
     if (rc < 0) raise_for(rc, "check");
     return n;
 }
