@@ -27,7 +27,7 @@ namespace lr {
 namespace {
 
 #ifndef LR_QBATCH_BWD
-#define LR_QBATCH_BWD 256           // staging round of the QUAD shape: one Gaussian per thread
+#define LR_QBATCH_BWD 128           // staging round of the QUAD shape (per-wave accumulator columns: 24 KB of LDS at 128)
 #endif
 constexpr int BATCH2 = 64;          // staged Gaussians per round of the 2-wave shape (7 KB of LDS per workgroup, so registers --
                                     // 7 waves per SIMD -- and not LDS limit the occupancy; 3 % faster than 128, 32 is slower)
@@ -142,9 +142,9 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     }
 }
 
-// 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 27 KB of LDS per workgroup allow 5
+// 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
 template <bool QUAD>
-__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 5 : 7, 8)))
+__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 4 : 7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
@@ -157,7 +157,12 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
-    __shared__ float s_acc[BATCH][12];  // per-batch gradient accumulator (all waves add into it); columns below
+    // per-batch gradient accumulator, columns below.  2-wave shape: both waves add into the same entry -- two operands,
+    // so the float sum does not depend on which wave comes first.  QUAD shape: four waves would make it depend on the
+    // arrival order (run-to-run different bits), so every wave adds into its OWN copy and the flush sums the four copies
+    // in a fixed order: the backward is bit-repeatable at every image size.
+    constexpr int NACC = QUAD ? 4 : 1;
+    __shared__ float s_acc[BATCH][NACC][12];
     constexpr int NWAVES = QUAD ? 4 : 2;
     __shared__ uint32_t s_wlast[NWAVES];
 
@@ -234,8 +239,12 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
         }
+        if (tid < BATCH) {
 #pragma unroll
-        for (int k = 0; k < 12; k++) if (tid < BATCH) s_acc[tid][k] = 0.f;
+            for (int a = 0; a < NACC; a++)
+#pragma unroll
+                for (int k = 0; k < 12; k++) s_acc[tid][a][k] = 0.f;
+        }
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
@@ -280,7 +289,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
                 asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
                 // one address per lane: columns col_a, col_a + 4, col_a + 8 (the db partial of each row has its own column)
-                float* dst = s_acc[j] + col_a;
+                float* dst = s_acc[j][QUAD ? w : 0] + col_a;
                 if (row_leader) {
                     atomicAdd(dst, ra);
                     atomicAdd(dst + 4, rb);
@@ -293,7 +302,14 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             // every instance owns one 48-byte slot: plain stores, no atomics, and the per-Gaussian sum in
             // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed).  The factors that
             // are constant per Gaussian (opacity, conic entries, -0.5, the NDC scale of backward.cu:473-474) go in here.
-            const float* a9 = s_acc[tid];              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db
+            float a9[12];                              // sums of D dx, D dy, D dx^2, D dx dy, D dy^2, D, dr, dg, db (x4)
+#pragma unroll
+            for (int k = 0; k < 12; k++) {
+                float v = s_acc[tid][0][k];
+#pragma unroll
+                for (int a = 1; a < NACC; a++) v += s_acc[tid][a][k];      // fixed order over the waves
+                a9[k] = v;
+            }
             const float4 q0 = s_q0[tid], q1 = s_q1[tid];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.y;

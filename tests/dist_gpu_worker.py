@@ -1,0 +1,45 @@
+"""Worker of tests/test_gpu_distributed.py: one rank of a data-parallel multi-view step on the real HIP path.
+Launched by torch.distributed.run with LR_DIST_BACKEND=gloo so that several ranks can share the one GPU of a gpurun box
+(RCCL refuses two ranks on one device; gloo stages the same all_reduce calls through the host).  Rank 0 writes the reduced
+gradient bucket to argv[1]."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from luciddreamer_amd import cameras, parallel, synthetic       # noqa: E402
+
+
+def build(dev, n_views, world, rank, chunks):
+    cloud = {k: v.to(dev).requires_grad_(True) for k, v in synthetic.make_cloud(30_000, "band", 6).items()}
+    path = cameras.rotate360_path(256, 160, n_views=n_views)
+    mine = [path[i].to(dev) for i in parallel.shard_views(n_views, rank, world)]
+    g = synthetic.upstream_grad(160, 256).to(dev)
+    named = {"means3D": cloud["means3D"], "scales": cloud["scales"], "rotations": cloud["rotations"],
+             "opacity": cloud["opacities"], "sh": cloud["shs"]}
+    step = parallel.ChunkedViewStep(mine, [g] * len(mine), named, 3, torch.zeros(3, device=dev), 400_000, n_streams=2,
+                                    chunks=chunks)
+    return step, torch.zeros(30_000, 3, device=dev)
+
+
+def main():
+    out = sys.argv[1]
+    rank, world, dev = parallel.init_distributed()
+    step, m2d = build(dev, 8, world, rank, None)
+    assert len(step.buckets) == (parallel.REDUCE_CHUNKS if world > 1 else 1)
+    for _ in range(2):                                   # twice: buckets are re-zeroed, works re-issued
+        step.run(m2d)
+    step.check()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"flat": step.grads.flat.cpu(), "world": world, "backend": torch.distributed.get_backend() if world > 1 else None},
+                   out)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

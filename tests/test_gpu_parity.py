@@ -332,6 +332,25 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     assert np.abs(m1 - m2).max() <= 1e-5 * np.abs(m1).max()
 
 
+@pytest.mark.parametrize("W,H", [(512, 512), (1920, 1080)])
+def test_backward_is_bit_repeatable(hip_device, W, H):
+    """a deterministic backward is the default.  512x512 uses the 4-wave (quadrant) shape of the blend
+    backward -- every wave sums into its own LDS copy, the copies are added in a fixed order -- and 1080p the 2-wave shape
+    (two operands: order-free); the per-Gaussian sums run in a fixed order.  Ten runs, identical bits."""
+    cam, cloud = hp.box_setup(60_000, W, H, seed=5, scale_mult=2.0)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.2, 0.1, 0.0])
+    first = None
+    for _ in range(10):
+        out = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+        flat = np.concatenate([out["grads"][k].ravel() for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations")])
+        if first is None:
+            first = flat
+            assert np.abs(flat).max() > 0
+        else:
+            assert np.array_equal(first.view(np.uint32), flat.view(np.uint32))
+
+
 def test_view_batch_equals_autograd_accumulation(hip_device):
     """parallel.ViewBatch (lr_views_accumulate: one C call, internal streams) == per-view autograd accumulation."""
     from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
