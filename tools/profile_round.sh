@@ -11,6 +11,6 @@ cd $R
 python bench.py > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/${TAG}_bench_c3.err
 tail -c 600 gpurun_out/${TAG}_bench_c3.json
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_default -o ${TAG}_default -- python $R/bench.py --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_streams1 -o ${TAG}_streams1 -- python $R/bench.py --no-cpu-baseline --streams 1 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_default -o ${TAG}_default -- python $R/bench.py --no-cpu-baseline --no-extras > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_streams1 -o ${TAG}_streams1 -- python $R/bench.py --no-cpu-baseline --no-extras --streams 1 > /dev/null 2>&1
 ls $R/gpurun_out/prof_${TAG}_default $R/gpurun_out/prof_${TAG}_streams1
