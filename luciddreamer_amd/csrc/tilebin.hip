@@ -24,7 +24,7 @@
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
 //   k_tile_sort / _mid / _big            one workgroup per bin sorts its words in LDS (bitonic network; three size
-//                                        classes: <= 256 entries by one wave, <= 2048, <= 16384 with 128 KB of LDS;
+//                                        classes: <= 256 entries by one wave, <= 4096 (bucket sort), <= 16384 with 128 KB of LDS;
 //                                        beyond that in place in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
@@ -173,6 +173,10 @@ __device__ __forceinline__ void part_chunk(uint32_t V, int nb, int b, uint32_t& 
     if (end > V) end = V;
 }
 
+// LDS index of a bin's counter: one pad word per 16 bins.  bin_prefix_to_lds gives every thread 16 CONSECUTIVE bins; without
+// the pad the lanes of a wave would hit only two of the 32 banks (16-word stride).
+__device__ __forceinline__ int bin_slot(int bin) { return bin + (bin >> 4); }
+
 template <class F>
 __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, int gy, const uint32_t* __restrict__ vis_list,
                                            const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
@@ -239,7 +243,7 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
 // Exclusive prefix over the bins, evaluated by every scatter workgroup for itself (1024 threads x up to 16 consecutive
 // bins: one block-wide scan) into its LDS cursor array; workgroup 0 also publishes bin_start and the per-tile ranges
 // (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
-// builds the queue of bins that only k_tile_sort_big can take (more than 2048 entries).
+// builds the queue of bins that only k_tile_sort_big can take (more than 4096 entries).
 __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total,
                                                   const uint32_t* __restrict__ row, uint32_t* s_bin, bool publish,
                                                   uint32_t* __restrict__ bin_start, uint2* __restrict__ ranges,
@@ -267,7 +271,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
     for (int i = 0; i < PER; i++) {
         const int bin = base + i;
         if (bin < bins) {
-            s_bin[bin] = run + row[bin];
+            s_bin[bin_slot(bin)] = run + row[bin];
             if (publish) {
                 bin_start[bin] = run;
                 if (sub_shift == 0) ranges[bin] = v[i] ? make_uint2(run, run + v[i]) : make_uint2(0u, 0u);   // empty: (0,0), :311
@@ -312,7 +316,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
        uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ inst_gid,
        unsigned long long* __restrict__ words)
 {
-    extern __shared__ uint32_t s_bin[];                  // [bins]
+    extern __shared__ uint32_t s_bin[];                  // [bins + bins / 16 + 1], indexed through bin_slot()
     const uint32_t V = hdr->num_compact;
     const int nb = part_active_blocks(V);
     const int b = (int)blockIdx.x;
@@ -320,7 +324,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     const uint32_t cap = hdr->num_sorted;                // instances that fit the binning buffer (all, in exact mode)
     uint32_t* row = part_hist + (size_t)b * bins;
     if (MODE == 0) {
-        for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[i] = 0u;
+        for (int i = threadIdx.x; i < bins + (bins >> 4) + 1; i += PART_THREADS) s_bin[i] = 0u;
     } else {
         bin_prefix_to_lds(bins, gx * gy, sub_shift, bin_total, row, s_bin, b == 0, bin_start, ranges, big_queue);
     }
@@ -331,15 +335,15 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     if (MODE == 0) {
         walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
                    [&](uint32_t tile, uint32_t slot, uint32_t gid, uint32_t) {
-                       if (slot < cap) { atomicAdd(&s_bin[tile >> sub_shift], 1u); inst_gid[slot] = gid; }
+                       if (slot < cap) { atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u); inst_gid[slot] = gid; }
                    });
         __syncthreads();
-        for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[i];
+        for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[bin_slot(i)];
     } else {
         walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
                    [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
                        if (slot < cap) {
-                           const uint32_t pos = atomicAdd(&s_bin[tile >> sub_shift], 1u);
+                           const uint32_t pos = atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u);
                            words[pos] = ((unsigned long long)(tile & sub_mask) << (31 + slot_bits)) |
                                         ((unsigned long long)dbits << slot_bits) | (unsigned long long)slot;
                        }
@@ -416,7 +420,7 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
 }
 
 // Three size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
-// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_mid: 256 threads per bin, up to 2048 entries (16 KB).
+// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_mid: 512 threads per bin, up to 4096 entries (bucket sort).
 // k_tile_sort_big: fed by the queue the scatter kernel built, 1024 threads, up to 16384 entries in 128 KB of LDS, beyond
 // that in place in global memory.  All three are always launched; workgroups whose bin belongs to another class return.
 __global__ void __launch_bounds__(64)
@@ -436,22 +440,105 @@ k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_
     write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 64u, point_list, ranges);
 }
 
+// Middle class: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
+// are mapped monotonically onto ~n buckets between the bin's smallest and largest key, counted, scanned and scattered
+// with LDS atomics (order inside a bucket arbitrary), then every bucket -- one or two entries on average -- is put in
+// order by an insertion sort on the full 64-bit word.  Any monotone map keeps the result exact; the map only decides how
+// evenly the buckets fill.  A bin whose keys pile up (a bucket of more than 32 entries, e.g. many splats at one depth)
+// falls back to the bitonic network.  ~8 barriers instead of the network's 66-78 at these sizes.
 __global__ void __launch_bounds__(TSORT_THREADS)
 k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
                 const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
                 uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
-    // one workgroup per bin, like k_tile_sort (measured against a queue-fed persistent grid: 0.07 vs 0.14 ms on the dense
-    // 1 M cloud at 1080p -- the queue loop chains three dependent global loads per bin)
-    __shared__ unsigned long long s_a[TSORT_MID_LDS];
+    constexpr int PER = TSORT_MID_LDS / TSORT_THREADS;                // 8 items / buckets per thread
+    __shared__ unsigned long long s_out[TSORT_MID_LDS];
+    __shared__ uint32_t s_cnt[TSORT_MID_LDS];
+    __shared__ unsigned long long s_red[2 * (TSORT_THREADS / 64)];
+    __shared__ uint32_t s_wave[TSORT_THREADS / 64];
+    __shared__ uint32_t s_bad;
     const int bin = (int)blockIdx.x;
     const uint32_t n = bin_total[bin];
     if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_MID_LDS) return;
     const uint32_t start = bin_start[bin];
-    for (uint32_t i = threadIdx.x; i < n; i += TSORT_THREADS) s_a[i] = words[start + i];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long item[PER];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
+        item[k] = i < n ? words[start + i] : ~0ull;
+        if (i < n) { const unsigned long long key = item[k] >> slot_bits; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) s_cnt[tid + k * TSORT_THREADS] = 0u;
+    if (tid == 0) s_bad = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { s_red[2 * w] = kmin; s_red[2 * w + 1] = kmax; }
     __syncthreads();
-    bitonic_sort(s_a, n, threadIdx.x, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
-    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, (uint32_t)TSORT_THREADS, point_list, ranges);
+#pragma unroll
+    for (int i = 0; i < TSORT_THREADS / 64; i++) { kmin = s_red[2 * i] < kmin ? s_red[2 * i] : kmin; kmax = s_red[2 * i + 1] > kmax ? s_red[2 * i + 1] : kmax; }
+    // bucket of a key: floor((key - kmin) * nbuckets / (span + 1)), evaluated in double (span < 2^34: exact enough to be
+    // monotone, which is all that is needed)
+    uint32_t nb = 1;
+    while (nb < n) nb <<= 1;                                          // <= TSORT_MID_LDS
+    const double scale = (double)nb / ((double)(kmax - kmin) + 1.0);
+    uint32_t bucket[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
+        uint32_t bk = (uint32_t)((double)((item[k] >> slot_bits) - kmin) * scale);
+        bucket[k] = bk < nb ? bk : nb - 1;
+        if (i < n) atomicAdd(&s_cnt[bucket[k]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the bucket counts: thread t owns buckets [t*PER, t*PER+PER)
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { c[k] = s_cnt[tid * PER + k]; sum += c[k]; if (c[k] > 32u) s_bad = 1u; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - sum;
+    for (int j = 0; j < w; j++) run += s_wave[j];
+    const uint32_t my_first = run;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += c[k]; }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
+        if (i < n) s_out[atomicAdd(&s_cnt[bucket[k]], 1u)] = item[k];
+    }
+    __syncthreads();
+    if (s_bad) {
+        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+    } else {
+        // each thread orders its own PER consecutive buckets: the segment [my_first, run)
+        uint32_t lo = my_first;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t hi = lo + c[k];
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const unsigned long long x = s_out[i];
+                uint32_t j = i;
+                while (j > lo && s_out[j - 1] > x) { s_out[j] = s_out[j - 1]; j--; }
+                s_out[j] = x;
+            }
+            lo = hi;
+        }
+        __syncthreads();
+    }
+    write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
 }
 
 __global__ void __launch_bounds__(1024)
@@ -511,9 +598,9 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (!attr_done) {
         // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort 128 KB
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PART_BINS_MAX * 4) != hipSuccess ||
+                                (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PART_BINS_MAX * 4) != hipSuccess ||
+                                (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 TSORT_BIG_LDS * 8) != hipSuccess)
             return -1;
@@ -526,7 +613,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     long long nb = ((long long)P + PART_MIN_GAUSS - 1) / PART_MIN_GAUSS;
     if (nb < 1) nb = 1;
     if (nb > PART_BLOCKS_MAX) nb = PART_BLOCKS_MAX;
-    const size_t lds = (size_t)pp.bins * 4;
+    const size_t lds = ((size_t)pp.bins + pp.bins / 16 + 1) * 4;
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
