@@ -24,7 +24,7 @@
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
 //   k_tile_sort / _mid / _big            one workgroup per bin sorts its words in LDS (bitonic network; three size
-//                                        classes: <= 256 entries by one wave, <= 4096 (bucket sort), <= 16384 with 128 KB of LDS;
+//                                        classes: <= 256 entries by one wave, <= 2048 (network / bucket sort), <= 16384 with 128 KB of LDS;
 //                                        beyond that in place in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
@@ -243,7 +243,7 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
 // Exclusive prefix over the bins, evaluated by every scatter workgroup for itself (1024 threads x up to 16 consecutive
 // bins: one block-wide scan) into its LDS cursor array; workgroup 0 also publishes bin_start and the per-tile ranges
 // (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
-// builds the queue of bins that only k_tile_sort_big can take (more than 4096 entries).
+// builds the queue of bins that only k_tile_sort_big can take (more than 2048 entries).
 __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total,
                                                   const uint32_t* __restrict__ row, uint32_t* s_bin, bool publish,
                                                   uint32_t* __restrict__ bin_start, uint2* __restrict__ ranges,
@@ -420,7 +420,7 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
 }
 
 // Three size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
-// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_mid: 512 threads per bin, up to 4096 entries (bucket sort).
+// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_mid: 256 threads per bin, up to 2048 entries (network up to 768, bucket sort above).
 // k_tile_sort_big: fed by the queue the scatter kernel built, 1024 threads, up to 16384 entries in 128 KB of LDS, beyond
 // that in place in global memory.  All three are always launched; workgroups whose bin belongs to another class return.
 __global__ void __launch_bounds__(64)
@@ -445,7 +445,8 @@ k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_
 // with LDS atomics (order inside a bucket arbitrary), then every bucket -- one or two entries on average -- is put in
 // order by an insertion sort on the full 64-bit word.  Any monotone map keeps the result exact; the map only decides how
 // evenly the buckets fill.  A bin whose keys pile up (a bucket of more than 32 entries, e.g. many splats at one depth)
-// falls back to the bitonic network.  ~8 barriers instead of the network's 66-78 at these sizes.
+// falls back to the bitonic network.  ~8 barriers instead of the network's 66 at these sizes (dense 512^2 view: 0.145 ->
+// 0.052 ms).
 __global__ void __launch_bounds__(TSORT_THREADS)
 k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
                 const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
@@ -462,6 +463,15 @@ k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
     if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_MID_LDS) return;
     const uint32_t start = bin_start[bin];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (n <= (uint32_t)TSORT_BUCKET_MIN) {
+        // few hundred entries (the dense 1080p / 1440p clouds): the network's ~45 cheap stages beat the bucket sort's
+        // scan + two atomic passes (measured on the dense 1 M cloud at 1080p: 0.087 vs 0.152 ms per view)
+        for (uint32_t i = tid; i < n; i += TSORT_THREADS) s_out[i] = words[start + i];
+        __syncthreads();
+        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+        write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+        return;
+    }
     unsigned long long item[PER];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
