@@ -84,9 +84,9 @@ constexpr int PART_BLOCKS_MAX = 256;        // workgroups of the count / scatter
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MIN_GAUSS = 1024;        // emitting Gaussians per workgroup before another workgroup is used
 constexpr int TSORT_LDS = 256;              // bin entries sorted by one wave (2 KB of LDS)
-constexpr int TSORT_THREADS = 256;          // threads of the middle class
-constexpr int TSORT_MID_LDS = 2048;         // ... its bin entries (16 KB of words + 8 KB of bucket counters)
-constexpr int TSORT_BUCKET_MIN = 768;       // ... above this many entries a bucket sort, below the bitonic network
+constexpr int TSORT_NET_LDS = 768;          // bin entries of the 256-thread bitonic class (6 KB of LDS)
+constexpr int TSORT_THREADS = 512;          // threads of the bucket-sort class
+constexpr int TSORT_MID_LDS = 4096;         // ... its bin entries (32 KB of words + 16 KB of bucket counters)
 constexpr int TSORT_BIG_LDS = 16384;        // ... the large-bin kernel (128 KB); beyond: in place in global memory
 constexpr int TSORT_BIG_BLOCKS = 256;
 struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)

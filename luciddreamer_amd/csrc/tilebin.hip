@@ -23,14 +23,14 @@
 //                                        the same walk again; every hit takes the next free position of its bin from
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
-//   k_tile_sort / _mid / _big            one workgroup per bin sorts its words in LDS (bitonic network; three size
-//                                        classes: <= 256 entries by one wave, <= 2048 (network / bucket sort), <= 16384 with 128 KB of LDS;
+//   k_tile_sort / _net / _mid / _big     one workgroup per bin sorts its words in LDS (bitonic network; three size
+//                                        classes: <= 256 entries by one wave, <= 768 (network), <= 4096 (bucket sort), <= 16384 with 128 KB of LDS;
 //                                        beyond that in place in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
 //                                        repeatable, whatever order the scatter produced.
 //
-// 8 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
+// 9 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
 // atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
 #include "common.h"
 
@@ -243,7 +243,7 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
 // Exclusive prefix over the bins, evaluated by every scatter workgroup for itself (1024 threads x up to 16 consecutive
 // bins: one block-wide scan) into its LDS cursor array; workgroup 0 also publishes bin_start and the per-tile ranges
 // (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
-// builds the queue of bins that only k_tile_sort_big can take (more than 2048 entries).
+// builds the queue of bins that only k_tile_sort_big can take (more than 4096 entries).
 __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total,
                                                   const uint32_t* __restrict__ row, uint32_t* s_bin, bool publish,
                                                   uint32_t* __restrict__ bin_start, uint2* __restrict__ ranges,
@@ -419,8 +419,9 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
     }
 }
 
-// Three size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
-// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_mid: 256 threads per bin, up to 2048 entries (network up to 768, bucket sort above).
+// Four size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
+// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_net: 256 threads, up to 768 entries, bitonic network.
+// k_tile_sort_mid: 512 threads, up to 4096 entries, bucket sort.
 // k_tile_sort_big: fed by the queue the scatter kernel built, 1024 threads, up to 16384 entries in 128 KB of LDS, beyond
 // that in place in global memory.  All three are always launched; workgroups whose bin belongs to another class return.
 __global__ void __launch_bounds__(64)
@@ -440,7 +441,26 @@ k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_
     write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 64u, point_list, ranges);
 }
 
-// Middle class: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
+// 257..768 entries (the tiles of the dense 1080p / 1440p clouds): the bitonic network on 256 threads in 6 KB of LDS.  At
+// these sizes its ~45 cheap stages beat the bucket sort's scan and two atomic passes (dense 1 M cloud at 1080p: 0.087 vs
+// 0.152 ms per view), and the small footprint keeps many bins resident per CU.
+__global__ void __launch_bounds__(256)
+k_tile_sort_net(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+                const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
+                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+{
+    __shared__ unsigned long long s_a[TSORT_NET_LDS];
+    const int bin = (int)blockIdx.x;
+    const uint32_t n = bin_total[bin];
+    if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_NET_LDS) return;
+    const uint32_t start = bin_start[bin];
+    for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
+    __syncthreads();
+    bitonic_sort(s_a, n, threadIdx.x, 256u, [] { __syncthreads(); });
+    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
+}
+
+// 769..4096 entries: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
 // are mapped monotonically onto ~n buckets between the bin's smallest and largest key, counted, scanned and scattered
 // with LDS atomics (order inside a bucket arbitrary), then every bucket -- one or two entries on average -- is put in
 // order by an insertion sort on the full 64-bit word.  Any monotone map keeps the result exact; the map only decides how
@@ -460,18 +480,9 @@ k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
     __shared__ uint32_t s_bad;
     const int bin = (int)blockIdx.x;
     const uint32_t n = bin_total[bin];
-    if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_MID_LDS) return;
+    if (n <= (uint32_t)TSORT_NET_LDS || n > (uint32_t)TSORT_MID_LDS) return;
     const uint32_t start = bin_start[bin];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (n <= (uint32_t)TSORT_BUCKET_MIN) {
-        // few hundred entries (the dense 1080p / 1440p clouds): the network's ~45 cheap stages beat the bucket sort's
-        // scan + two atomic passes (measured on the dense 1 M cloud at 1080p: 0.087 vs 0.152 ms per view)
-        for (uint32_t i = tid; i < n; i += TSORT_THREADS) s_out[i] = words[start + i];
-        __syncthreads();
-        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
-        write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
-        return;
-    }
     unsigned long long item[PER];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
@@ -636,6 +647,8 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                        inst_gid, words);
     if (t) t->mark(3, s);
     hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(64), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
+                       bin_start, bin_total, words, point_list, ranges);
+    hipLaunchKernelGGL(k_tile_sort_net, dim3(pp.bins), dim3(256), 0, s, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges);
     hipLaunchKernelGGL(k_tile_sort_mid, dim3(pp.bins), dim3(TSORT_THREADS), 0, s, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges);
