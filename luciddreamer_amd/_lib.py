@@ -9,8 +9,8 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LUCID_RASTER_LIB selects another build of the same library (e.g. one compiled with different tuning macros)
-LIB_PATH = os.environ.get("LUCID_RASTER_LIB") or os.path.join(_HERE, "lib", "liblucid_raster.so")
+# one library instance per process: the compiled binding (_C_ext) is linked against this very file ($ORIGIN/lib)
+LIB_PATH = os.path.join(_HERE, "lib", "liblucid_raster.so")
 
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
