@@ -240,23 +240,29 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
     }
 }
 
-// Exclusive prefix over the bins, evaluated by every scatter workgroup for itself (1024 threads x up to 16 consecutive
-// bins: one block-wide scan) into its LDS cursor array; workgroup 0 also publishes bin_start and the per-tile ranges
-// (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
+// Exclusive prefix over the bins, evaluated by every scatter workgroup for itself, into its LDS cursor array
+// (cursor = bin start + this workgroup's base inside the bin); workgroup 0 also publishes bin_start and the per-tile
+// ranges (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
 // builds the queue of bins that only k_tile_sort_big can take (more than 4096 entries).
+// Global memory is touched with consecutive lanes on consecutive words only (the totals are staged through the cursor
+// array; a thread then scans 16 CONSECUTIVE bins out of LDS, conflict-free thanks to bin_slot's padding): with each thread
+// loading its own 64-byte run straight from global memory this prologue cost 12 us of the kernel's 32.
 __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int sub_shift, const uint32_t* __restrict__ bin_total,
                                                   const uint32_t* __restrict__ row, uint32_t* s_bin, bool publish,
                                                   uint32_t* __restrict__ bin_start, uint2* __restrict__ ranges,
                                                   uint32_t* __restrict__ big_queue)
 {
-    constexpr int PER = PART_BINS_MAX / PART_THREADS;     // 16 consecutive bins per thread
+    constexpr int PER = PART_BINS_MAX / PART_THREADS;     // 16 consecutive bins per thread in the scan phase
     __shared__ uint32_t s_wave[PART_THREADS / 64];
+    __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[bin_slot(i)] = bin_total[i];
+    __syncthreads();
     const int base = threadIdx.x * PER;
     uint32_t v[PER];
     uint32_t sum = 0;
 #pragma unroll
-    for (int i = 0; i < PER; i++) { v[i] = (base + i < bins) ? bin_total[base + i] : 0u; sum += v[i]; }
+    for (int i = 0; i < PER; i++) { v[i] = (base + i < bins) ? s_bin[bin_slot(base + i)] : 0u; sum += v[i]; }
     uint32_t inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -267,22 +273,11 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
     __syncthreads();
     uint32_t run = inc - sum;
     for (int j = 0; j < w; j++) run += s_wave[j];
-#pragma unroll
-    for (int i = 0; i < PER; i++) {
-        const int bin = base + i;
-        if (bin < bins) {
-            s_bin[bin_slot(bin)] = run + row[bin];
-            if (publish) {
-                bin_start[bin] = run;
-                if (sub_shift == 0) ranges[bin] = v[i] ? make_uint2(run, run + v[i]) : make_uint2(0u, 0u);   // empty: (0,0), :311
-            }
-        }
-        run += v[i];
-    }
+    if (threadIdx.x == PART_THREADS - 1) s_total = run + sum;
+    uint32_t q = 0, nbig = 0;
     if (publish) {
-        // the queue of bins for k_tile_sort_big, in bin order, by a second block scan (no atomics: returning
-        // global atomics on one word cost ~45 ns each on this part, and a dense 512^2 view queues every tile)
-        uint32_t nbig = 0;
+        // the queue of bins for k_tile_sort_big, in bin order, by a second block scan (no atomics: returning global
+        // atomics on one word cost ~45 ns each on this part, and a dense 512^2 view queues every tile)
 #pragma unroll
         for (int i = 0; i < PER; i++) nbig += v[i] > (uint32_t)TSORT_MID_LDS ? 1u : 0u;
         uint32_t binc = nbig;
@@ -294,15 +289,40 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
         __syncthreads();                                  // s_wave is reused
         if (lane == 63) s_wave[w] = binc;
         __syncthreads();
-        uint32_t q = binc - nbig;
+        q = binc - nbig;
         for (int j = 0; j < w; j++) q += s_wave[j];
-#pragma unroll
-        for (int i = 0; i < PER; i++)
-            if (v[i] > (uint32_t)TSORT_MID_LDS) big_queue[1 + q++] = (uint32_t)(base + i);
-        if (threadIdx.x == PART_THREADS - 1) big_queue[0] = q;
-        if (sub_shift != 0)
-            for (int t = threadIdx.x; t < num_tiles; t += PART_THREADS) ranges[t] = make_uint2(0u, 0u);
     }
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const int bin = base + i;
+        if (bin < bins) {
+            s_bin[bin_slot(bin)] = run;                   // exclusive start of the bin
+            if (publish && v[i] > (uint32_t)TSORT_MID_LDS) big_queue[1 + q++] = (uint32_t)bin;
+        }
+        run += v[i];
+    }
+    if (publish && threadIdx.x == PART_THREADS - 1) big_queue[0] = q;
+    __syncthreads();
+    // coalesced pass: starts (and the next bin's start = this bin's end) out of LDS, this workgroup's row from global
+    for (int i0 = 0; i0 < bins; i0 += PART_THREADS) {
+        const int i = i0 + threadIdx.x;
+        uint32_t st = 0, en = 0, r = 0;
+        if (i < bins) {
+            st = s_bin[bin_slot(i)];
+            en = (i + 1 < bins) ? s_bin[bin_slot(i + 1)] : s_total;
+            r = row[i];
+        }
+        __syncthreads();                                  // every start of this sweep is read before any is advanced
+        if (i < bins) {
+            s_bin[bin_slot(i)] = st + r;
+            if (publish) {
+                bin_start[i] = st;
+                if (sub_shift == 0) ranges[i] = en > st ? make_uint2(st, en) : make_uint2(0u, 0u);   // empty: (0,0), :311
+            }
+        }
+    }
+    if (publish && sub_shift != 0)
+        for (int t = threadIdx.x; t < num_tiles; t += PART_THREADS) ranges[t] = make_uint2(0u, 0u);
 }
 
 // MODE 0: count (per-workgroup bin histogram -> part_hist[b][bin]; also records inst_gid[slot])
@@ -326,6 +346,9 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     if (MODE == 0) {
         for (int i = threadIdx.x; i < bins + (bins >> 4) + 1; i += PART_THREADS) s_bin[i] = 0u;
     } else {
+#ifdef LR_DBG_NOPROLOGUE
+        if (b == 0)
+#endif
         bin_prefix_to_lds(bins, gx * gy, sub_shift, bin_total, row, s_bin, b == 0, bin_start, ranges, big_queue);
     }
     __syncthreads();
@@ -344,6 +367,9 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
                    [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
                        if (slot < cap) {
                            const uint32_t pos = atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u);
+#ifdef LR_DBG_NOSTORE
+                           if (pos == 0xFFFFFFFFu)
+#endif
                            words[pos] = ((unsigned long long)(tile & sub_mask) << (31 + slot_bits)) |
                                         ((unsigned long long)dbits << slot_bits) | (unsigned long long)slot;
                        }

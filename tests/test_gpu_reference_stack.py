@@ -75,7 +75,7 @@ def test_c5_at_size_loss_curve_parity(hip_device):
     rates (R/arguments.py:19-34) towards fixed RGB + depth targets rendered from a perturbed copy.  Loss = the
     reference's 0.8 L1 + 0.2 (1 - SSIM) plus 0.1 L1 on depth (which must contribute no gradient).  The device run goes
     through the unchanged reference classes over our rasterizer for all 200 iterations.  The checker is the same loop
-    on the host through the oracle: free-running for the first LR_C5_HOST_ITERS iterations (default 60; 200 runs the
+    on the host through the oracle: free-running for the first LR_C5_HOST_ITERS iterations (default 40; 200 runs the
     whole curve and takes ~5 min of host time -- measured once: max relative distance 1.5e-3, mean 1.5e-4), and at
     iterations 100, 150 and 200 the oracle re-evaluates the loss at the DEVICE run's own parameters.
 
@@ -83,7 +83,7 @@ def test_c5_at_size_loss_curve_parity(hip_device):
     +-lr, so Gaussians whose gradient is float noise walk in unrelated directions in two correct implementations."""
     P, W, H = 1_000_000, 512, 512
     iters = int(os.environ.get("LR_C5_ITERS", "200"))
-    host_iters = min(iters, int(os.environ.get("LR_C5_HOST_ITERS", "60")))
+    host_iters = min(iters, int(os.environ.get("LR_C5_HOST_ITERS", "40")))
     cams = cameras.lookaround_path(W, H, n_views=8, max_yaw_deg=8.0, max_pitch_deg=4.0)
     base, hidden = _perturbed(P, 41)
     targets, depths = _targets(hidden, cams)
