@@ -6,9 +6,9 @@ Restates the matrix conventions of the reference (nothing here is on the hot pat
     inverse(view)[3, :3]: /root/reference/scene/cameras.py:58-61, 64-75 (MiniCam)
   - FoVy from FoVx and the aspect ratio: /root/reference/utils/camera.py:27-29
   - camera paths "rotate360" (pure rotations about the world y axis at the origin) and
-    "lookaround": the poses stored in /root/reference/cameras/rotate360.json are
-    R_y(theta_i), theta_i = i * 0.5 deg, i = 0..719, no translation; they are regenerated
-    analytically here so that nothing reads /root/reference at run time.
+    "lookaround": the poses stored in /root/reference/cameras/rotate360.json are, after the reference's
+    OpenGL -> COLMAP axis flip, R_y(-theta_i), theta_i = i * 0.5 deg, i = 0..719, no translation; they are
+    regenerated analytically here so that nothing reads /root/reference at run time.
 """
 import math
 from typing import List, NamedTuple
@@ -109,12 +109,15 @@ def _rot_x(phi):
 
 
 def rotate360_path(width, height, n_views=30, n_frames=720, fovx=FOVX_DEFAULT) -> List[MiniCam]:
-    """Every (n_frames // n_views)-th pose of the 720-frame rotate360 preset."""
+    """Every (n_frames // n_views)-th pose of the 720-frame rotate360 preset.  Frame i of
+    /root/reference/cameras/rotate360.json is the OpenGL-convention c2w [[c,0,s],[0,-1,0],[s,0,-c]], theta = i * 0.5 deg;
+    after the reference's axis flip `c2w[:3, 1:3] *= -1` (scene/dataset_readers.py:267) that is R_y(-theta) in the COLMAP
+    convention make_camera expects (tests/test_oracle_golden.py checks the match against the JSON)."""
     stride = max(1, n_frames // n_views)
     cams = []
     for i in list(range(0, n_frames, stride))[:n_views]:
         c2w = np.eye(4)
-        c2w[:3, :3] = _rot_y(2.0 * math.pi * i / n_frames)
+        c2w[:3, :3] = _rot_y(-2.0 * math.pi * i / n_frames)
         cams.append(make_camera(c2w, width, height, fovx))
     return cams
 
