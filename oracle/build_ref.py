@@ -82,6 +82,62 @@ def build(force=False, verbose=False):
     return LIB
 
 
+SHIM_HIP = os.path.join(HERE, "ref_shim_hip")
+LIB_DEV = os.path.join(OUT_DIR, "libref_raster_gfx950.so")
+
+
+def build_device(force=False, verbose=False):
+    """The same reference sources compiled by hipcc for gfx950 (streamed through ONE whitespace rewrite: the reference
+    spells its launches `kernel << <grid, block >> > (...)`, which nvcc accepts and clang does not -> `kernel<<<grid, block>>>(`) against
+    oracle/ref_shim_hip/ (CUDA header names -> ROCm headers, cub -> hipCUB, the GLM subset with device qualifiers) plus
+    ref_capi_hip.cpp.  Output: oracle/_ref/libref_raster_gfx950.so -- the reference's own kernels on the MI355X, used as a
+    device-side checker at full sizes and as the `reference_on_device` baseline of bench.py.  Returns the path or None."""
+    if not available():
+        return LIB_DEV if os.path.exists(LIB_DEV) else None
+    deps = list(SOURCES) + [os.path.abspath(__file__)]
+    for root in (SHIM_HIP, os.path.join(SHIM, "glm")):
+        for r, _, files in os.walk(root):
+            deps += [os.path.join(r, f) for f in files]
+    if not force and os.path.exists(LIB_DEV) and all(os.path.getmtime(d) <= os.path.getmtime(LIB_DEV) for d in deps):
+        return LIB_DEV
+    os.makedirs(OUT_DIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-I", SHIM_HIP,
+             "-I", os.path.join(RAST, "cuda_rasterizer"), "-I", KNN]
+    objs = []
+    procs = []
+    # clang's HIP driver reads its input twice (host and device pass), so the rewritten text cannot come through a pipe:
+    # it goes to a scratch file under the git-ignored oracle/_ref/ that is deleted as soon as the object exists
+    tmp = []
+    try:
+        for src in SOURCES + [os.path.join(SHIM_HIP, "ref_capi_hip.cpp")]:
+            obj = os.path.join(OUT_DIR, "dev_" + os.path.basename(src) + ".o")
+            text = open(src, encoding="utf-8", errors="replace").read()
+            text = LAUNCH.sub(r"\1<<<\2>>>(", text)
+            scratch = os.path.join(OUT_DIR, "scratch_" + os.path.basename(src) + ".hip")
+            with open(scratch, "w") as f:
+                f.write(f'#line 1 "{src}"\n{text}')
+            tmp.append(scratch)
+            cmd = [hipcc, "-x", "hip", "-c", scratch, "-o", obj] + flags + ["-iquote", os.path.dirname(src)]
+            if verbose:
+                print(" ".join(cmd), f"  # = {src}", flush=True)
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+            objs.append(obj)
+        for src, pr in procs:
+            out, _ = pr.communicate()
+            if pr.returncode != 0:
+                raise RuntimeError(f"hipcc failed on {src}:\n{out[-6000:]}")
+    finally:
+        for t in tmp:
+            if os.path.exists(t):
+                os.remove(t)
+    subprocess.run([hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_DEV] + objs, check=True)
+    for o in objs:
+        os.remove(o)
+    return LIB_DEV
+
+
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print(path if path else "reference sources not found and no prebuilt oracle/_ref/libref_raster.so")
+    print(build_device(force="--force" in sys.argv, verbose=True))
