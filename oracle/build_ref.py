@@ -102,7 +102,9 @@ def build_device(force=False, verbose=False):
         return LIB_DEV
     os.makedirs(OUT_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-w", "-I", SHIM_HIP,
+    # -ffp-contract=off like the host build: float32 in source operand order (with contraction the per-Gaussian records
+    # differ in their last bits and ~0.1 % of the pixels of a 1080p view move by more than 1e-5)
+    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-w", "-I", SHIM_HIP,
              "-I", os.path.join(RAST, "cuda_rasterizer"), "-I", KNN]
     objs = []
     procs = []
