@@ -425,10 +425,46 @@ def run_cpu_baseline(cloud, cam, degree, H, W):
                     break
     except OSError:
         pass
-    return {"value": round(1.0 / med, 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"median of {len(times)} views fwd+bwd of the same workload after 1 warm-up view "
-                      f"({fwd_med:.2f}s fwd + {med - fwd_med:.2f}s bwd), OpenMP over {cores} host threads",
-            "cpu_model": model}
+    out = {"value": round(1.0 / med, 4), "unit": "views/s", "cores": cores, "kind": "port",
+           "sample": f"median of {len(times)} views fwd+bwd of the same workload after 1 warm-up view "
+                     f"({fwd_med:.2f}s fwd + {med - fwd_med:.2f}s bwd), OpenMP over {cores} host threads",
+           "cpu_model": model}
+    # Second baseline of the same leg, when the build container shipped it: the reference's OWN kernels (forward.cu,
+    # backward.cu, rasterizer_impl.cu compiled by hipcc for gfx950, oracle/build_ref.py build_device()) on this GPU, driven
+    # the way its binding drives them: zero-filled outputs and gradients, one blocking read-back per forward, legacy stream.
+    try:
+        from oracle import ref_device
+        if ref_device.available():
+            dev = torch.device("cuda:0")
+            c = {k: v.to(dev).contiguous() for k, v in cloud.items()}
+            gd = torch.from_numpy(g).to(dev)
+            bg = torch.zeros(3, device=dev)
+            r = ref_device.Renderer()
+            cd = [x.to(dev) for x in cams]
+
+            def ref_view(x):
+                r.forward(bg, c["means3D"], None, c["opacities"], c["scales"], c["rotations"], 1.0, None,
+                          x.world_view_transform.contiguous(), x.full_proj_transform.contiguous(), math.tan(x.FoVx * 0.5),
+                          math.tan(x.FoVy * 0.5), H, W, c["shs"], degree, x.camera_center.contiguous(), sync=False)
+                r.backward(gd, sync=False)
+            for x in cd[:3]:
+                ref_view(x)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            for _ in range(3):
+                for x in cd:
+                    ref_view(x)
+                    n += 1
+            ref_device.lib().refdev_sync()
+            dt = time.perf_counter() - t0
+            out["reference_kernels_on_this_gpu"] = {
+                "value": round(n / dt, 1), "unit": "views/s",
+                "what": "the reference's own CUDA sources compiled by hipcc for gfx950 (oracle/_ref, -O3, hipCUB sort/scan), "
+                        f"{n} views fwd+bwd of the same workload, one stream, its own host read-back per forward"}
+    except Exception as e:                                   # the baseline is optional evidence, never a reason to fail
+        out["reference_kernels_on_this_gpu"] = {"error": str(e)[:200]}
+    return out
 
 
 if __name__ == "__main__":
