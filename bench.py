@@ -460,7 +460,7 @@ def run_cpu_baseline(cloud, cam, degree, H, W):
             dt = time.perf_counter() - t0
             out["reference_kernels_on_this_gpu"] = {
                 "value": round(n / dt, 1), "unit": "views/s",
-                "what": "the reference's own CUDA sources compiled by hipcc for gfx950 (oracle/_ref, -O3, hipCUB sort/scan), "
+                "what": "the reference's own CUDA sources compiled by hipcc for gfx950 (oracle/_ref, -O3 -ffp-contract=off, hipCUB sort/scan), "
                         f"{n} views fwd+bwd of the same workload, one stream, its own host read-back per forward"}
     except Exception as e:                                   # the baseline is optional evidence, never a reason to fail
         out["reference_kernels_on_this_gpu"] = {"error": str(e)[:200]}
