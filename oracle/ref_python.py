@@ -124,6 +124,49 @@ class CpuRasterizerExtension:
         return torch.from_numpy(self._mark(self._np(means3D), self._np(viewmatrix), self._np(projmatrix)))
 
 
+class DeviceRasterizerExtension:
+    """Stand-in for `_C` over the reference's OWN kernels on the GPU (oracle/ref_device.py: oracle/_ref compiled by hipcc
+    for gfx950): the reference's Python op, render() and GaussianModel then run end to end on device tensors with nothing of
+    this repository's rasterizer involved -- the device-side checker of the loss-curve tests."""
+
+    def __init__(self):
+        from . import ref_device
+        self._rd = ref_device
+        self._pool, self._live, self._next = [], {}, 1
+
+    @staticmethod
+    def _c(t):
+        return None if t is None or t.numel() == 0 else t.detach().contiguous()
+
+    def rasterize_gaussians(self, bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                            viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                            prefiltered, debug):
+        c = self._c
+        r = self._pool.pop() if self._pool else self._rd.Renderer()
+        R, color, depth, radii = r.forward(c(bg), c(means3D), c(colors), c(opacity), c(scales), c(rotations), scale_modifier,
+                                           c(cov3D_precomp), c(viewmatrix), c(projmatrix), tan_fovx, tan_fovy, image_height,
+                                           image_width, c(sh), degree, c(campos), prefiltered)
+        handle = self._next
+        self._next += 1
+        self._live[handle] = r
+        for old in [h for h in self._live if h <= handle - 4]:
+            self._pool.append(self._live.pop(old))
+        tag = torch.tensor([handle], dtype=torch.int64)
+        return R, color, depth, radii, tag, tag.clone(), tag.clone()
+
+    def rasterize_gaussians_backward(self, bg, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                     viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_depth, sh, degree,
+                                     campos, geomBuffer, R, binningBuffer, imageBuffer, debug):
+        r = self._live.pop(int(geomBuffer[0]))
+        g = r.backward(dL_dout_color.contiguous())
+        out = tuple(t.clone() for t in g[:8])
+        self._pool.append(r)
+        return out
+
+    def mark_visible(self, means3D, viewmatrix, projmatrix):
+        raise NotImplementedError("markVisible is not wired for the device-side reference")
+
+
 def _stub(name, **attrs):
     m = types.ModuleType(name)
     for k, v in attrs.items():
@@ -142,7 +185,8 @@ def reference_modules(rasterizer="ours"):
 
     rasterizer="ours": `depth_diff_gaussian_rasterization_min` / `simple_knn` resolve to this repository (device run).
     rasterizer="ref" | "port": the reference's own Python op over a CPU stand-in for `_C`; simple_knn._C.distCUDA2 is
-    served by the same backend.  Enter `cuda_as_cpu()` as well when no device is involved."""
+    served by the same backend.  Enter `cuda_as_cpu()` as well when no device is involved.
+    rasterizer="refdev": the reference's own Python op over its own kernels on the GPU (oracle/ref_device.py)."""
     base = root()
     if base is None:
         raise RuntimeError("neither /root/reference nor oracle/_ref/py is present")
@@ -162,7 +206,11 @@ def reference_modules(rasterizer="ours"):
         sys.modules["scene"] = scene
         if rasterizer != "ours":
             from . import oracle, ref
-            ext = CpuRasterizerExtension(rasterizer)
+            if rasterizer == "refdev":
+                from . import ref_device
+                ext = DeviceRasterizerExtension()
+            else:
+                ext = CpuRasterizerExtension(rasterizer)
             spec = importlib.util.spec_from_file_location(
                 "depth_diff_gaussian_rasterization_min", os.path.join(base, RAST_PY),
                 submodule_search_locations=[os.path.dirname(os.path.join(base, RAST_PY))])
@@ -170,10 +218,14 @@ def reference_modules(rasterizer="ours"):
             sys.modules["depth_diff_gaussian_rasterization_min"] = pkg
             sys.modules["depth_diff_gaussian_rasterization_min._C"] = ext
             spec.loader.exec_module(pkg)                  # runs `from . import _C` -> the stand-in
-            d2 = ref.dist2 if rasterizer == "ref" else oracle.dist2
+            if rasterizer == "refdev":
+                dist_fn = lambda pts: ref_device.dist2(pts.detach())
+            else:
+                d2 = ref.dist2 if rasterizer == "ref" else oracle.dist2
+                dist_fn = lambda pts: torch.from_numpy(d2(pts.detach().cpu().numpy()))
             knn = _stub("simple_knn")
             knn.__path__ = []
-            knn._C = _stub("simple_knn._C", distCUDA2=lambda pts: torch.from_numpy(d2(pts.detach().cpu().numpy())))
+            knn._C = _stub("simple_knn._C", distCUDA2=dist_fn)
             sys.modules["simple_knn"], sys.modules["simple_knn._C"] = knn, knn._C
         sys.path.insert(0, base)
         ns = types.SimpleNamespace()

@@ -81,7 +81,7 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
 def stack(rasterizer):
     """reference modules + (for CPU backends) the cuda->cpu mapping, as one context."""
     with rp.reference_modules(rasterizer) as R:
-        if rasterizer == "ours":
+        if rasterizer in ("ours", "refdev"):
             yield R, torch.device("cuda:0")
         else:
             with rp.cuda_as_cpu():
