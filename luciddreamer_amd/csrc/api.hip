@@ -286,7 +286,7 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
                 float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,
                 float* dL_dscale, float* dL_drot, int debug, long long binning_capacity,
                 unsigned int accumulate_mask, void* stream_, hipEvent_t wait_before_accumulate,
-                const RawArgs* raw = nullptr, hipStream_t accum_stream = nullptr, hipEvent_t blend_done = nullptr)
+                const RawArgs* raw = nullptr)
 {
     using namespace lr;
     (void)dL_depths;   // ignored, as in the reference (backward.cu:457-464, 539-554 commented out)
@@ -344,13 +344,6 @@ static int backward_core(int P, int D, int M, int R, const float* background, in
     LR_DEBUG_SYNC(debug, s, "render backward");
     // another stream may still be accumulating into the same gradient tensors (lr_views_accumulate)
     if (wait_before_accumulate != nullptr) LR_HIP_CHECK(hipStreamWaitEvent(s, wait_before_accumulate, 0));
-    // multi-view step: everything that touches the caller's gradient tensors runs on ONE dedicated stream, in view order
-    // (so the accumulation needs no event chain and the view's own stream is free for its next forward)
-    if (accum_stream != nullptr) {
-        LR_HIP_CHECK(hipEventRecord(blend_done, s));
-        LR_HIP_CHECK(hipStreamWaitEvent(accum_stream, blend_done, 0));
-        s = accum_stream;
-    }
     {   // tensors in write mode are zero-filled here (one launch); accumulate-mode tensors are left alone
         ProfScope ps(ST_OUT_ZERO, s);
         const unsigned long long Pn = (unsigned long long)P;
@@ -446,14 +439,9 @@ char* slice_alloc(size_t bytes, void* user)
     return bytes <= c->bytes ? c->ptr : nullptr;
 }
 // internal streams / events of the multi-view entry points: one set per device, created on first use
-constexpr int kMaxViewSlots = 2 * kMaxViewStreams;       // two workspace slots per view stream (see views_core)
 struct ViewStreamSet {
     hipStream_t streams[kMaxViewStreams] = { nullptr, nullptr, nullptr, nullptr };
-    hipStream_t accum = nullptr;                          // per-Gaussian backward of every view, in view order
-    hipEvent_t fork = nullptr, join_accum = nullptr;
-    hipEvent_t join[kMaxViewStreams] = {};
-    hipEvent_t blend_done[kMaxViewSlots] = {};            // ring: blend backward of the view in this slot is enqueued
-    hipEvent_t slot_free[kMaxViewSlots] = {};             // ring: the per-Gaussian backward that read this slot is done
+    hipEvent_t events[2 * kMaxViewStreams + 2] = {};
 };
 std::mutex g_view_mu;
 std::map<int, ViewStreamSet> g_view_sets;
@@ -463,7 +451,7 @@ size_t lr_views_workspace_bytes(int P, int width, int height, long long binning_
 {
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
-    return view_slot_layout(P, width, height, binning_capacity).total * (size_t)(2 * n_streams);
+    return view_slot_layout(P, width, height, binning_capacity).total * (size_t)n_streams;
 }
 
 static int views_core(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
@@ -488,14 +476,10 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
     if (!acc_mean2D || !acc_opacity || !acc_mean3D) return fail(LR_ERR_INVALID_ARG, "acc_mean2D/acc_opacity/acc_mean3D are required");
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
-    const int n_slots = 2 * n_streams;             // slots the caller's workspace was sized for (lr_views_check reads all)
+    const int n_slots = n_streams;                 // slots the caller's workspace was sized for (lr_views_check reads all)
     if (n_streams > n_views) n_streams = n_views;
     const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity, with_loss);
-    // Two workspace slots per view stream: view v renders on stream v % n_streams into slot v % (2 n_streams), so the
-    // per-Gaussian backward of view v (on the accumulation stream) can still read its slot while the same view stream
-    // already runs the forward of view v + n_streams.
-    const int use_slots = 2 * n_streams;
-    if (workspace_bytes < SL.total * (size_t)use_slots) return fail(LR_ERR_INVALID_ARG, "workspace too small (lr_views_workspace_bytes)");
+    if (workspace_bytes < SL.total * (size_t)n_streams) return fail(LR_ERR_INVALID_ARG, "workspace too small (lr_views_workspace_bytes)");
 
     int device = 0;
     LR_HIP_CHECK(hipGetDevice(&device));
@@ -503,17 +487,15 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
     {
         std::lock_guard<std::mutex> lock(g_view_mu);
         vs = &g_view_sets[device];                              // std::map: the address stays valid
-        auto ev = [](hipEvent_t& e) { return e ? hipSuccess : hipEventCreateWithFlags(&e, hipEventDisableTiming); };
-        for (int i = 0; i < n_streams; i++) {
+        for (int i = 0; i < n_streams; i++)
             if (!vs->streams[i]) LR_HIP_CHECK(hipStreamCreateWithFlags(&vs->streams[i], hipStreamNonBlocking));
-            LR_HIP_CHECK(ev(vs->join[i]));
-        }
-        if (!vs->accum) LR_HIP_CHECK(hipStreamCreateWithFlags(&vs->accum, hipStreamNonBlocking));
-        LR_HIP_CHECK(ev(vs->fork));
-        LR_HIP_CHECK(ev(vs->join_accum));
-        for (int i = 0; i < kMaxViewSlots; i++) { LR_HIP_CHECK(ev(vs->blend_done[i])); LR_HIP_CHECK(ev(vs->slot_free[i])); }
+        for (int i = 0; i < 2 * kMaxViewStreams + 2; i++)
+            if (!vs->events[i]) LR_HIP_CHECK(hipEventCreateWithFlags(&vs->events[i], hipEventDisableTiming));
     }
     hipStream_t* const g_view_streams = vs->streams;
+    hipEvent_t ev_fork = vs->events[0];
+    hipEvent_t* ev_bwd = &vs->events[1];                        // ring of n_streams + 1 "accumulation done" events
+    hipEvent_t* ev_join = &vs->events[2 + kMaxViewStreams];
 
     // sticky per-slot overflow words (see GeomHeader::sticky_overflow) start at zero -- in EVERY slot of the workspace,
     // also the ones a step with fewer views than streams leaves unused (lr_views_check reads them all); fork the streams
@@ -521,9 +503,8 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
         GeomHeader* hdr = reinterpret_cast<GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
         LR_HIP_CHECK(hipMemsetAsync(&hdr->sticky_overflow, 0, 4, caller));
     }
-    LR_HIP_CHECK(hipEventRecord(vs->fork, caller));
-    for (int i = 0; i < n_streams; i++) LR_HIP_CHECK(hipStreamWaitEvent(g_view_streams[i], vs->fork, 0));
-    LR_HIP_CHECK(hipStreamWaitEvent(vs->accum, vs->fork, 0));
+    LR_HIP_CHECK(hipEventRecord(ev_fork, caller));
+    for (int i = 0; i < n_streams; i++) LR_HIP_CHECK(hipStreamWaitEvent(g_view_streams[i], ev_fork, 0));
 
     unsigned int mask = LR_ACC_MEAN2D | LR_ACC_OPACITY | LR_ACC_MEAN3D;
     if (acc_color) mask |= LR_ACC_COLOR;
@@ -533,14 +514,11 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
     if (acc_rot) mask |= LR_ACC_ROT;
 
     struct CorunScope { CorunScope(bool on) { set_blend_corun(on); } ~CorunScope() { set_blend_corun(false); } } corun(n_streams > 1);
-    // one view stream = strictly serial execution (bench.py's per-stage timing leg): no separate accumulation stream
-    hipStream_t accum = n_streams > 1 ? vs->accum : nullptr;
+    hipEvent_t prev = nullptr;
     for (int v = 0; v < n_views; v++) {
-        const int si = v % n_streams, sl = v % use_slots;
+        const int si = v % n_streams;
         hipStream_t s = g_view_streams[si];
-        char* slot = workspace + (size_t)sl * SL.total;
-        // the slot's previous tenant (view v - use_slots) must have been consumed by its per-Gaussian backward
-        if (v >= use_slots) LR_HIP_CHECK(hipStreamWaitEvent(s, vs->slot_free[sl], 0));
+        char* slot = workspace + (size_t)si * SL.total;
         SliceCookie cg = { slot + SL.geom, SL.img - SL.geom }, ci = { slot + SL.img, SL.bin - SL.img },
                     cb = { slot + SL.bin, SL.color - SL.bin };
         float* color = (out_color && out_color[v]) ? out_color[v] : reinterpret_cast<float*>(slot + SL.color);
@@ -560,22 +538,20 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
             launch_loss_backward(3, height, width, color, targets[v], lambda_dssim, nullptr, slot + SL.loss_ws, gimg, s);
             view_grad = gimg;
         }
-        // blend backward on the view's stream; zero-fill + per-Gaussian backward (the only kernels that touch the caller's
-        // gradient tensors) on the accumulation stream, in view order
         rc = backward_core(P, D, M, LR_NUM_RENDERED_ON_DEVICE, background, width, height, means3D, shs, colors_precomp,
                            scales, scale_modifier, rotations, cov3D_precomp, viewmatrices[v], projmatrices[v],
                            cam_positions[v], tan_fovx[v], tan_fovy[v], radii, slot + SL.geom, slot + SL.bin, slot + SL.img,
                            view_grad, nullptr, acc_mean2D, nullptr, acc_opacity, acc_color, acc_mean3D, acc_cov3D, acc_sh,
-                           acc_scale, acc_rot, 0, binning_capacity, mask, s, nullptr, nullptr, accum, vs->blend_done[sl]);
+                           acc_scale, acc_rot, 0, binning_capacity, mask, s, prev);
         if (rc < 0) return rc;
-        LR_HIP_CHECK(hipEventRecord(vs->slot_free[sl], accum ? accum : s));
+        hipEvent_t done = ev_bwd[v % (n_streams + 1)];
+        LR_HIP_CHECK(hipEventRecord(done, s));
+        prev = done;
     }
     for (int i = 0; i < n_streams; i++) {
-        LR_HIP_CHECK(hipEventRecord(vs->join[i], g_view_streams[i]));
-        LR_HIP_CHECK(hipStreamWaitEvent(caller, vs->join[i], 0));
+        LR_HIP_CHECK(hipEventRecord(ev_join[i], g_view_streams[i]));
+        LR_HIP_CHECK(hipStreamWaitEvent(caller, ev_join[i], 0));
     }
-    LR_HIP_CHECK(hipEventRecord(vs->join_accum, vs->accum));
-    LR_HIP_CHECK(hipStreamWaitEvent(caller, vs->join_accum, 0));
     return 0;
 }
 
@@ -601,7 +577,7 @@ size_t lr_views_train_workspace_bytes(int P, int width, int height, long long bi
 {
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
-    return view_slot_layout(P, width, height, binning_capacity, true).total * (size_t)(2 * n_streams);
+    return view_slot_layout(P, width, height, binning_capacity, true).total * (size_t)n_streams;
 }
 
 int lr_views_train_accumulate(int n_views, const float* const* viewmatrices, const float* const* projmatrices,
@@ -631,8 +607,7 @@ static int views_check_core(const char* workspace, int P, int width, int height,
     if (n_streams < 1) n_streams = 1;
     if (n_streams > kMaxViewStreams) n_streams = kMaxViewStreams;
     const ViewSlot SL = view_slot_layout(P, width, height, binning_capacity, with_loss);
-    uint32_t flags[kMaxViewSlots] = {};
-    n_streams *= 2;                                  // two slots per view stream (views_core)
+    uint32_t flags[kMaxViewStreams] = { 0, 0, 0, 0 };
     for (int i = 0; i < n_streams; i++) {
         const GeomHeader* hdr = reinterpret_cast<const GeomHeader*>(workspace + (size_t)i * SL.total + SL.geom);
         LR_HIP_CHECK(hipMemcpyAsync(&flags[i], &hdr->sticky_overflow, 4, hipMemcpyDeviceToHost, s));

@@ -230,7 +230,7 @@ class ViewStreams:
 
 class ViewBatch:
     """One C call per step for a fixed list of views (lr_views_accumulate): forward + backward of every view,
-    gradients accumulated in place, views alternated over internal HIP streams (per-Gaussian backward of all views on one more).  The per-view upstream
+    gradients accumulated in place, views alternated over internal HIP streams.  The per-view upstream
     gradients dL/dcolor are given up front (a training loop that needs the rendered image to form its loss uses
     the autograd op, optionally with ViewStreams, instead).
 
