@@ -322,252 +322,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------------
-// MFMA shape: the per-candidate wave reduction leaves the VALU.  One 8x8 quadrant per wave, one pixel per lane (as QUAD).
-// For a (pixel, Gaussian) pair only the two scalars that vary per pair are formed -- D = G dL/dalpha and W = alpha T --
-// and every sum the reference accumulates with atomics is a moment of one of them over the pixels:
-//     sum D {1, X, Y, X^2, X Y, Y^2}   (X, Y = pixel coordinates relative to the tile origin: small exact integers)
-//     sum W {dL/dr, dL/dg, dL/db}
-// from which the flush forms sum D dx, sum D dx^2, ... with dx = (x_gauss - tile_x0) - X.  That is a matrix product
-// [candidates x pixels] . [pixels x 9] and runs on the matrix cores, which the VALU-bound kernel otherwise leaves idle:
-// a wave parks D and W of 8 candidates in 16 LDS rows (2 ds_write_b32 per candidate), then
-// v_mfma_f32_16x16x4_f32 x 16 (exact f32, a k-ordered fma chain: deterministic) multiplies the 16 x 64 block by the
-// wave's constant 64 x 16 feature matrix (16 VGPRs per lane, built once per tile).  Rows 0-7 x columns 0-5 are the D
-// moments, rows 8-15 x columns 6-8 the W sums; the other products are computed and ignored.  Per candidate and quadrant:
-// 2 MFMA issues + 1/2 ds_read_b128 + 1/2 ds_add instead of 3 products, 5 moment products and the 29-instruction
-// reduce8 / row_sum tree.
-// ---------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int MF_BATCH = 64;          // staged Gaussians per round
-constexpr int MF_VS = 68;             // floats per parking row: 64 pixels + 4 (rows 16 B apart in the banks: conflict-free b128 reads)
-constexpr int MF_ACC = 37;            // floats per s_acc entry: 4 waves x 9 columns + 1 (odd stride)
-
-struct MfPix {
-    float T, A, last_alpha, lcdl, dLr, dLg, dLb, pxf;
-    uint32_t last;
-};
-
-__device__ __forceinline__ void mf_pixel(MfPix& p, const float Ap, const float Bd, const float Cdd, const float gx, const float op,
-                                         const float cr, const float cg, const float cb, const uint32_t pos, float& D, float& Wt)
-{
-    p.A = p.A + p.last_alpha * (p.lcdl - p.A);
-    asm volatile("" : "+v"(p.A));
-    const float dx = gx - p.pxf;
-    const float power = gauss_power1(Ap, Bd, Cdd, dx);
-    const float Graw = __expf(power);
-    const float araw = fminf(0.99f, op * Graw);
-    const bool v = pos < p.last && power <= 0.0f && araw >= 1.0f / 255.0f;       // backward.cu:500-515
-    const float alpha = v ? araw : 0.f;
-    const float G = v ? Graw : 0.f;
-    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-    p.T = p.T * rinv;
-    Wt = alpha * p.T;
-    const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;
-    p.lcdl = cdl;
-    p.last_alpha = alpha;
-    D = G * ((cdl - p.A) * p.T);
-}
-
-// the group of (up to) 8 parked candidates -> s_acc.  jv: lane g holds the staged index of slot g.
-__device__ __forceinline__ void mf_flush(const float* __restrict__ vrow /* this wave's rows + (l&15)*MF_VS + 16*(l>>4) */,
-                                         const float (&bmat)[16], const int n, const int jv, float* __restrict__ acc_w /* s_acc + 9 w */,
-                                         const int l)
-{
-    const float4* r4 = reinterpret_cast<const float4*>(vrow);
-    const float4 a0 = r4[0], a1 = r4[1], a2 = r4[2], a3 = r4[3];
-    f32x4 c0 = { 0.f, 0.f, 0.f, 0.f }, c1 = { 0.f, 0.f, 0.f, 0.f };
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bmat[0], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bmat[1], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bmat[2], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bmat[3], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bmat[4], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bmat[5], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bmat[6], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bmat[7], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.x, bmat[8], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.y, bmat[9], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.z, bmat[10], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2.w, bmat[11], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.x, bmat[12], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.y, bmat[13], c1, 0, 0, 0);
-    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.z, bmat[14], c0, 0, 0, 0);
-    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3.w, bmat[15], c1, 0, 0, 0);
-    // lane (col = l & 15, h = l >> 4) holds rows 4 h + r: h < 2 -> D moments of slot 4 h + r (columns 0-5),
-    // h >= 2 -> W sums of slot 4 (h - 2) + r (columns 6-8)
-    const int col = l & 15, h = l >> 4;
-    const bool mine = h < 2 ? col < 6 : (col >= 6 && col < 9);
-    const int g0 = 4 * (h & 1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const int j = __builtin_amdgcn_ds_bpermute(4 * (g0 + r), jv);
-        if (mine && g0 + r < n) atomicAdd(acc_w + j * MF_ACC + col, c0[r] + c1[r]);
-    }
-}
-
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
-k_render_bwd_mf(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
-                const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
-                const float* __restrict__ bg, const float* __restrict__ final_Ts,
-                const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
-{
-    constexpr int BATCH = MF_BATCH;
-    __shared__ float4 s_q0[BATCH];      // x, y, Ap, Bp           (as k_render_bwd)
-    __shared__ float4 s_q1[BATCH];      // Cp, opacity, qmax, -
-    __shared__ float4 s_q2[BATCH];      // r, g, b, -
-    __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
-    __shared__ uint32_t s_id[BATCH];
-    __shared__ float s_acc[BATCH * MF_ACC];                    // [staged][wave][9 columns]: every wave adds into its own copy
-    __shared__ __attribute__((aligned(16))) float s_v[4][16][MF_VS];          // parking rows of each wave
-    __shared__ uint32_t s_wlast[4];
-
-    const int tile = blend_tile(tile_map, num_tiles);
-    if (tile < 0) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const int qx = (w & 1) * 8, qy = (w >> 1) * 8;               // quadrant origin inside the tile
-    const int x0 = tx * TILE_X + qx, y0 = ty * TILE_Y + qy;
-    const int px = x0 + (l & 7), py = y0 + (l >> 3);
-    const bool ins = px < W && py < H;
-    const float pyf = (float)py;
-    const float bx0 = (float)x0, by0 = (float)y0;
-    const size_t pix = (size_t)py * W + px;
-    const size_t N = (size_t)W * H;
-
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    if (total == 0) return;
-    const BinLayout BL = bin_layout((long long)hdr->bin_bound);
-    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
-    float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
-
-    MfPix P;
-    P.pxf = (float)px;
-    P.T = ins ? final_Ts[pix] : 0.f;
-    P.last = ins ? n_contrib[pix] : 0u;
-    P.dLr = P.dLg = P.dLb = 0.f;
-    if (ins) { P.dLr = dL_dpix[pix]; P.dLg = dL_dpix[N + pix]; P.dLb = dL_dpix[2 * N + pix]; }
-    P.A = bg[0] * P.dLr + bg[1] * P.dLg + bg[2] * P.dLb;
-    P.last_alpha = P.lcdl = 0.f;
-    const uint32_t wave_last = wave_max_u32(P.last);
-
-    // feature matrix B[k = pixel][column], lane (col = l & 15, h = l >> 4), step s <-> pixel p = 16 h + s of the quadrant
-    // (p = lane number of the pixel's owner): columns 0-5 = 1, X, Y, X^2, X Y, Y^2; 6-8 = dL/d{r,g,b} of that pixel
-    float bmat[16];
-    {
-        const int col = l & 15, h = l >> 4;
-#pragma unroll
-        for (int sidx = 0; sidx < 16; sidx++) {
-            const int p = 16 * h + sidx;
-            const float X = (float)(qx + (p & 7)), Y = (float)(qy + (p >> 3));
-            float v = 0.f;
-            if (col == 0) v = 1.0f;
-            else if (col == 1) v = X;
-            else if (col == 2) v = Y;
-            else if (col == 3) v = X * X;
-            else if (col == 4) v = X * Y;
-            else if (col == 5) v = Y * Y;
-            else if (col < 9) {
-                const int ppx = x0 + (p & 7), ppy = y0 + (p >> 3);
-                if (ppx < W && ppy < H) v = dL_dpix[(size_t)(col - 6) * N + (size_t)ppy * W + ppx];
-            }
-            bmat[sidx] = v;
-        }
-    }
-
-    if (l == 0) s_wlast[w] = wave_last;
-    __syncthreads();
-    uint32_t tile_last = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) tile_last = max(tile_last, s_wlast[i]);
-
-    float* const vw = &s_v[w][0][0];
-    const float* const vrow = vw + (l & 15) * MF_VS + 16 * (l >> 4);
-    float* const acc_w = s_acc + 9 * w;
-    const float tile_x0 = (float)(tx * TILE_X), tile_y0 = (float)(ty * TILE_Y);
-    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
-
-    for (int base = 0; base < total; base += BATCH) {
-        const int cnt = min(BATCH, total - base);
-        const int pos_hi = total - 1 - base;
-        const int pos_lo = pos_hi - (cnt - 1);
-        if ((uint32_t)pos_lo >= tile_last) {
-            if (tid < cnt) {
-                float4* slot = inst_grad + 3 * (size_t)point_list[range.x + (pos_hi - tid)];
-                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f); slot[1] = slot[0]; slot[2] = slot[0];
-            }
-            continue;
-        }
-        __syncthreads();
-        if (tid < cnt) {
-            const uint32_t e = point_list[range.x + (pos_hi - tid)];
-            const uint32_t id = inst_gid[e];
-            const float4* g = reinterpret_cast<const float4*>(rec + id);
-            const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
-            s_q1[tid] = make_float4(-0.5f * b.x, b.y, c.z, 0.f);
-            s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
-            s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
-            s_id[tid] = e;
-        }
-        for (int k = tid; k < BATCH * MF_ACC; k += 256) s_acc[k] = 0.f;
-        __syncthreads();
-
-        bool hit = false;
-        if (l < cnt) {
-            const uint32_t pos = (uint32_t)(pos_hi - l);
-            if (pos < wave_last) {
-                const float4 a = s_q0[l];
-                const float4 b = s_q1[l];
-                const float2 r = s_q3[l];
-                hit = box_hit(a.x, a.y, -2.0f * a.z, -a.w, -2.0f * b.x, r.x, r.y, b.z, bx0, bx0 + 7.0f, by0, by0 + 7.0f);
-            }
-        }
-        uint64_t mask = __ballot(hit);
-        int n = 0, jv = 0;
-        while (mask) {
-            const int j = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const uint32_t pos = (uint32_t)(pos_hi - j);
-            const float4 a = s_q0[j];
-            const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);
-            const float4 c = s_q2[j];
-            const float dys = a.y - pyf;
-            const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;
-            float D, Wt;
-            mf_pixel(P, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, D, Wt);
-            vw[n * MF_VS + l] = D;
-            vw[(8 + n) * MF_VS + l] = Wt;
-            asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(jv) : "s"(j), "s"(n) : "m0");      // lane n of jv <- j (both wave-uniform)
-            n++;
-            if (n == 8) { mf_flush(vrow, bmat, 8, jv, acc_w, l); n = 0; }
-        }
-        if (n > 0) mf_flush(vrow, bmat, n, jv, acc_w, l);
-        __syncthreads();
-        if (tid < cnt) {
-            float m[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const float* e = s_acc + tid * MF_ACC + k;
-                m[k] = (e[0] + e[9]) + (e[18] + e[27]);                 // fixed order over the four waves
-            }
-            const float4 q0 = s_q0[tid], q1 = s_q1[tid];
-            const float u = q0.x - tile_x0, v = q0.y - tile_y0;          // dx = u - X, dy = v - Y
-            const float Mx = u * m[0] - m[1], My = v * m[0] - m[2];
-            const float Mxx = u * Mx - (u * m[1] - m[3]);
-            const float Mxy = v * Mx - (u * m[2] - m[4]);
-            const float Myy = v * My - (v * m[2] - m[5]);
-            const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.y;
-            const float sx = o * Mx, sy = o * My, hh = -0.5f * o;
-            float4* slot = inst_grad + 3 * (size_t)s_id[tid];
-            slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, hh * Mxx, hh * Mxy);
-            slot[1] = make_float4(hh * Myy, m[0], m[6], m[7]);
-            slot[2] = make_float4(m[8], 0.f, 0.f, 0.f);
-        }
-    }
-}
-
 }  // namespace
 
 int blend_tile_map(int num_tiles)
@@ -607,11 +361,7 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     // under its VALU-bound loop: C3 with 3 streams 3985 -> 4150 views/s.  LR_BWD_LDS_PAD=<bytes> overrides (diagnostics).
     static const int forced_pad = [] { const char* e = getenv("LR_BWD_LDS_PAD"); return e ? atoi(e) : -1; }();
     const int pad = forced_pad >= 0 ? forced_pad : (g_blend_corun ? 8192 : 0);
-    static const int use_mf = [] { const char* e = getenv("LR_BWD_MFMA"); return e ? atoi(e) : 0; }();
-    if (use_mf)
-        hipLaunchKernelGGL(k_render_bwd_mf, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, bin_base, hdr);
-    else if (blend_quad(num_tiles))
+    if (blend_quad(num_tiles))
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, bin_base, hdr);
     else
