@@ -148,7 +148,6 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
     GaussRec* rec = reinterpret_cast<GaussRec*>(geom + GL.rec);
     uint8_t* clamped = reinterpret_cast<uint8_t*>(geom + GL.clamped);
     uint32_t* tiles_touched = reinterpret_cast<uint32_t*>(geom + GL.tiles_touched);
-    uint32_t* tiles_ref = reinterpret_cast<uint32_t*>(geom + GL.tiles_ref);
     uint32_t* vis_list = reinterpret_cast<uint32_t*>(geom + GL.vis_list);
     uint32_t* offsets = reinterpret_cast<uint32_t*>(geom + GL.offsets);
     uint32_t* goff = reinterpret_cast<uint32_t*>(geom + GL.goff);
@@ -161,8 +160,8 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
     uint32_t* bin_start = reinterpret_cast<uint32_t*>(img + IL.bin_start);
     uint32_t* big_queue = reinterpret_cast<uint32_t*>(img + IL.big_queue);
 
-    // header starts zeroed; the preprocess kernel fills in {capacity, P}
-    LR_HIP_CHECK(hipMemsetAsync(hdr, 0, offsetof(GeomHeader, sticky_overflow), s));
+    // header and the compaction's chunk sums start zeroed (one launch); the preprocess kernel fills in {capacity, P}
+    launch_forward_begin(hdr, scan_sums, P, s);
 
     ViewParams vp;
     vp.view = viewmatrix; vp.proj = projmatrix; vp.campos = cam_pos;
@@ -183,13 +182,13 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
         // K1: cull / project / conic / colour -> GaussRec, radii, tile counts
         { ProfScope ps(ST_PREPROCESS, s);
         launch_preprocess(vp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp,
-                          prefiltered != 0, radii, rec, clamped, tiles_touched, tiles_ref, nullptr, hdr,
-                          (uint32_t)binning_capacity, s); }
+                          prefiltered != 0, radii, rec, clamped, tiles_touched, nullptr, hdr,
+                          (uint32_t)binning_capacity, reinterpret_cast<uint32_t*>(scan_sums), s); }
         LR_DEBUG_SYNC(debug, s, "preprocess");
 
         // one scan in index order: the emitting Gaussians, their first instance slots, every count of the header
         { ProfScope ps(ST_COMPACT, s);
-        launch_compact(P, tiles_touched, tiles_ref, scan_sums, vis_list, offsets, goff, hdr, s); }
+        launch_compact(P, tiles_touched, scan_sums, vis_list, offsets, goff, hdr, s); }
         LR_DEBUG_SYNC(debug, s, "compact");
 
         if (binning_capacity == 0) {

@@ -94,7 +94,7 @@ PartPlan part_plan(int num_tiles);
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, goff, tiles_ref, vis_list, total;
+    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, goff, vis_list, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -102,7 +102,6 @@ inline GeomLayout geom_layout(int P) {
     L.rec = o;           o += align_up(Pz * sizeof(GaussRec));
     L.clamped = o;       o += align_up(Pz);
     L.tiles_touched = o; o += align_up(Pz * 4);      // instances each Gaussian emits (after exact tile culling)
-    L.tiles_ref = o;     o += align_up(Pz * 4);      // the reference's rectangle areas (their sum is num_rendered)
     L.vis_list = o;      o += align_up(Pz * 4);      // ids of the emitting Gaussians, index order (num_compact entries)
     L.offsets = o;       o += align_up(Pz * 4);      // first instance slot of vis_list[k]
     L.goff = o;          o += align_up(Pz * 4);      // the same, indexed by Gaussian id
@@ -202,6 +201,12 @@ __device__ __forceinline__ float gauss_power1(float Ap, float Bd, float Cdd, flo
 {
     return (Ap * dx + Bd) * dx + Cdd;
 }
+// The blend kernels stage Ap, Bp, Cp (and the cull threshold qmax, which box_hit compares with the same quadratic form)
+// multiplied by log2(e), so that G = exp(power) is one v_exp_f32 of the Horner value: the multiply of __expf leaves the
+// per-pixel step of both kernels.  `power <= 0` reads the same on the scaled value.
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float gauss_exp2(float power2) { return __builtin_amdgcn_exp2f(power2); }
 
 struct ViewParams {
     const float* view;      // device, 16 floats, flat index m[4*col+row] (auxiliary.h:58-77)
@@ -231,8 +236,10 @@ __device__ __forceinline__ float act_quat_inv_norm(float r, float x, float y, fl
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* tiles_ref, uint32_t* depth_key,
-                       GeomHeader* hdr, uint32_t binning_capacity, hipStream_t s);
+                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                       GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, hipStream_t s);
+// zeroes the per-call part of the header and the chunk sums that k_preprocess adds into (chunk_sums == nullptr there: none)
+void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
                          hipStream_t s);
 
@@ -245,8 +252,9 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
 
 // Order-preserving compaction of the Gaussians with tiles_touched != 0 (vis_list) fused with the exclusive scan of their
 // instance counts (offsets by rank, goff by Gaussian id); fills every count of the header: num_compact, num_rendered
-// (the reference's: sum of tiles_ref over all Gaussians), num_instances, num_sorted, overflow, bin_bound.
-void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, uint4* block_sums,
+// (the reference's: sum of the tile-rectangle areas over all Gaussians), num_instances, num_sorted, overflow, bin_bound.
+// block_sums: per SCAN_TILE chunk {emitting Gaussians, instances, rectangle areas, -}, accumulated by k_preprocess.
+void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s);
 // optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
 struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };

@@ -11,6 +11,7 @@
 // rectangles, depths and conics are bit-identical to the CPU oracle and the discrete outputs
 // (radii, num_rendered, per-tile order) can be compared exactly.  The kernel is HBM-bound, so the
 // missing FMAs cost nothing.
+#include <cstddef>
 #include "common.h"
 
 namespace lr {
@@ -149,8 +150,9 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
              const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
              const float* __restrict__ colors_precomp, int prefiltered,
              int* __restrict__ radii, GaussRec* __restrict__ rec, uint8_t* __restrict__ clamped,
-             uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ tiles_ref,
-             uint32_t* __restrict__ depth_key, GeomHeader* hdr, uint32_t binning_capacity)
+             uint32_t* __restrict__ tiles_touched,
+             uint32_t* __restrict__ depth_key, GeomHeader* hdr, uint32_t binning_capacity,
+             uint32_t* __restrict__ chunk_sums)
 {
     // Phase 1, one thread per Gaussian: the near-plane test (auxiliary.h:152-162).  Survivors are compacted, in index
     // order, into LDS; phase 2 runs the ~600-instruction projection / covariance / SH body on dense lanes only (on a
@@ -168,7 +170,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         const bool pass = in_range && !(vz1 <= 0.2f);
         if (in_range && !pass) {
             if (prefiltered) hdr->prefilter_trap = 1;
-            radii[gid] = 0; tiles_touched[gid] = 0; tiles_ref[gid] = 0;
+            radii[gid] = 0; tiles_touched[gid] = 0;
             if (depth_key) depth_key[gid] = 0xFFFFFFFFu;
         }
         const uint64_t m = __ballot(pass);
@@ -307,11 +309,34 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         }
     } while (false);
 
+    // this wave's share of the compaction's chunk sums (tilebin.hip k_compact_write): emitting Gaussians, instances,
+    // the reference's rectangle areas.  Integer atomics: the result does not depend on their order.  All 128 Gaussians
+    // of the workgroup lie in one SCAN_TILE chunk (zeroed by k_forward_begin); dead lanes carry zeros.
+    if (chunk_sums != nullptr) {
+        uint32_t inst = tiles_out, ref = area_ref;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { inst += __shfl_xor(inst, off); ref += __shfl_xor(ref, off); }
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(tiles_out != 0));
+        if ((threadIdx.x & 63) == 0 && ref != 0) {
+            uint32_t* dst = chunk_sums + 4 * ((size_t)blockIdx.x * PP_THREADS / SCAN_TILE);
+            if (cnt) { atomicAdd(dst, cnt); atomicAdd(dst + 1, inst); }
+            atomicAdd(dst + 2, ref);
+        }
+    }
     if (!live) return;
     radii[idx] = radius_out;
     tiles_touched[idx] = tiles_out;
-    tiles_ref[idx] = area_ref;
     if (depth_key) depth_key[idx] = key_out;
+}
+
+// first launch of a forward: the header's per-call part and the compaction's chunk sums start at zero (one launch
+// instead of a memset per region)
+__global__ void __launch_bounds__(256)
+k_forward_begin(uint32_t* __restrict__ hdr_words, int n_hdr, uint32_t* __restrict__ chunk_sums, int n_sums)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_hdr) hdr_words[i] = 0u;
+    if (i < n_sums) chunk_sums[i] = 0u;
 }
 
 __global__ void __launch_bounds__(256)
@@ -329,19 +354,29 @@ k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* tiles_ref, uint32_t* depth_key,
-                       GeomHeader* hdr, uint32_t binning_capacity, hipStream_t s)
+                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                       GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, hipStream_t s)
 {
+    static_assert(SCAN_TILE % PP_THREADS == 0, "a preprocess workgroup must lie inside one compaction chunk");
     if (vp.P <= 0) return;
     dim3 grid((vp.P + PP_THREADS - 1) / PP_THREADS), block(PP_THREADS);
     if (vp.raw)
         hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                            cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                           tiles_ref, depth_key, hdr, binning_capacity);
+                           depth_key, hdr, binning_capacity, chunk_sums);
     else
         hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                            cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                           tiles_ref, depth_key, hdr, binning_capacity);
+                           depth_key, hdr, binning_capacity, chunk_sums);
+}
+
+void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s)
+{
+    const int n_hdr = (int)(offsetof(GeomHeader, sticky_overflow) / 4);
+    const int n_sums = 4 * ((P + SCAN_TILE - 1) / SCAN_TILE);
+    const int n = n_hdr > n_sums ? n_hdr : n_sums;
+    hipLaunchKernelGGL(k_forward_begin, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint32_t*>(hdr), n_hdr,
+                       reinterpret_cast<uint32_t*>(chunk_sums), n_sums);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,

@@ -118,8 +118,8 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     p.A = p.A + p.last_alpha * (p.lcdl - p.A);                             // = last_alpha * lcdl + (1 - last_alpha) * A
     asm volatile("" : "+v"(p.A));
     const float dx = gx - p.pxf;
-    const float power = gauss_power1(Ap, Bd, Cdd, dx);
-    const float Graw = __expf(power);
+    const float power = gauss_power1(Ap, Bd, Cdd, dx);                     // log2(e) x the reference's power
+    const float Graw = gauss_exp2(power);
     const float araw = fminf(0.99f, op * Graw);
     // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped
     const bool v = pos < p.last && power <= 0.0f && araw >= 1.0f / 255.0f;
@@ -152,8 +152,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
 {
     constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
-    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
-    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, qmax (cull threshold), -   (Cp, opacity: one ds_read_b64)
+    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, qmax (cull threshold), -   (Cp, opacity: one ds_read_b64; Cp, qmax x log2 e)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
@@ -233,8 +233,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
-            s_q1[tid] = make_float4(-0.5f * b.x, b.y, c.z, 0.f);
+            s_q0[tid] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);        // as render_fwd.hip
+            s_q1[tid] = make_float4((-0.5f * LOG2E) * b.x, b.y, LOG2E * c.z, 0.f);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
@@ -258,7 +258,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                     const float4 a = s_q0[j];
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
+                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // conic x log2 e, like qmax
                     hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0, bx0 + 7.0f, by0, by1);
                     if (!QUAD) hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0 + 8.0f, bx1, by0, by1);
                 }
@@ -312,7 +312,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             }
             const float4 q0 = s_q0[tid], q1 = s_q1[tid];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
-            const float ca = -2.0f * q0.z, cb = -q0.w, cc = -2.0f * q1.x, o = q1.y;
+            const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;   // conic back from the scaled staging
             const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);

@@ -48,8 +48,8 @@ __device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const flo
                                           const float dx, const float op, const float cr, const float cg, const float cb,
                                           const float depth, const uint32_t pos0)
 {
-    const float power = gauss_power1(Ap, Bd, Cdd, dx);
-    const float alpha = fminf(0.99f, op * __expf(power));
+    const float power = gauss_power1(Ap, Bd, Cdd, dx);               // log2(e) x the reference's power (staged coefficients)
+    const float alpha = fminf(0.99f, op * gauss_exp2(power));
     const float test_T = p.T * (1.0f - alpha);
     // reference order of tests (forward.cu:331-347): power > 0 -> skip; alpha < 1/255 -> skip;
     // T*(1-alpha) < 1e-4 -> pixel done (this Gaussian is NOT blended)
@@ -74,8 +74,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ out_color, float* __restrict__ out_depth)
 {
-    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power)
-    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, depth, qmax (cull threshold)
+    __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity, depth, qmax (cull threshold, x log2 e)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a (edge minimiser slopes for box_hit)
     __shared__ int s_wdone[NWAVES];
@@ -107,8 +107,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = make_float4(a.x, a.y, -0.5f * a.z, -a.w);
-            s_q1[tid] = make_float4(-0.5f * b.x, b.y, c.y, c.z);
+            s_q0[tid] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            s_q1[tid] = make_float4((-0.5f * LOG2E) * b.x, b.y, c.y, LOG2E * c.z);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
         }
@@ -124,7 +124,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                     const float4 a = s_q0[j];
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // exact inverses
+                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // conic x log2 e, like qmax
                     hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.w, bx0, bx1, by0, by1);
                 }
             }

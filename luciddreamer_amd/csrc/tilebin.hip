@@ -9,7 +9,7 @@
 // MI355X design (round 2; the round-1 pipeline sorted the Gaussians globally by depth with 4 radix passes, emitted
 // in depth order and stably partitioned by tile with 2 more: 21 launches, 0.19 ms per C3 view for ~47 MB of bytes):
 //
-//   k_compact_reduce / k_compact_write   one scan over the P Gaussians gives, in INDEX order, the list of emitting
+//   k_compact_write (chunk sums: k_preprocess)   one scan over the P Gaussians gives, in INDEX order, the list of emitting
 //                                        Gaussians (vis_list), each one's first instance slot (offsets / goff) and
 //                                        every count of the header.  Instance slots are therefore contiguous per
 //                                        Gaussian and ascending with the Gaussian index.
@@ -57,27 +57,9 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 }
 
 // -------------------------------------------------------------------------------------------
-// compaction + instance offsets, index order (2 kernels).  block_sums[b] = {emitting Gaussians, instances,
-// reference rectangle areas} of block b.
+// compaction + instance offsets, index order.  block_sums[b] = {emitting Gaussians, instances, reference rectangle
+// areas} of chunk b, accumulated by k_preprocess (preprocess.hip).
 // -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SCAN_THREADS)
-k_compact_reduce(int P, const uint32_t* __restrict__ tiles_touched, const uint32_t* __restrict__ tiles_ref,
-                 uint4* __restrict__ block_sums)
-{
-    __shared__ uint32_t s_tmp[4];
-    const int base = blockIdx.x * SCAN_TILE;
-    uint32_t cnt = 0, inst = 0, sum_ref = 0;
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const int k = base + i * SCAN_THREADS + threadIdx.x;
-        if (k < P) { const uint32_t t = tiles_touched[k]; cnt += t != 0 ? 1u : 0u; inst += t; sum_ref += tiles_ref[k]; }
-    }
-    cnt = block_reduce_sum(cnt, s_tmp);
-    inst = block_reduce_sum(inst, s_tmp);
-    sum_ref = block_reduce_sum(sum_ref, s_tmp);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = make_uint4(cnt, inst, sum_ref, 0u);
-}
-
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
                 uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
@@ -626,11 +608,10 @@ PartPlan part_plan(int num_tiles)
     return p;
 }
 
-void launch_compact(int P, const uint32_t* tiles_touched, const uint32_t* tiles_ref, uint4* block_sums,
+void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
-    hipLaunchKernelGGL(k_compact_reduce, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, tiles_ref, block_sums);
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
                        offsets, goff, hdr);
 }

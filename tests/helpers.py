@@ -117,6 +117,31 @@ def compare_grads(hip_g, ref_g, names=None, rtol=GRAD_RTOL):
     return figures
 
 
+def compare_grads_by_row(hip, ref, P, names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"), max_outliers=32):
+    """The full-size bar: every gradient row within GRAD_RTOL of its tensor's maximum, except rows of Gaussians whose
+    footprint contains a pixel the oracle itself flags as sitting within rounding of a discrete threshold (alpha = 1/255,
+    T = 1e-4: "fragile") -- those within 1e-3, at most `max_outliers` per tensor, and each one must be located on such
+    a pixel.  Returns {tensor: (worst relative row error, outliers)}."""
+    st = ref["res"].stage()
+    fy, fx = np.nonzero(st["fragile"] != 0)
+    m2, radii = st["means2D"], ref["radii"]
+    report = {}
+    for k in names:
+        a = hip["grads"][k].reshape(P, -1)
+        b = ref["grads"][k].reshape(P, -1)
+        scale = float(np.abs(b).max())
+        row_err = np.abs(a - b).max(axis=1)
+        bad = np.nonzero(row_err > GRAD_RTOL * scale)[0]
+        report[k] = (f"{row_err.max() / scale:.2e}", len(bad))
+        assert len(bad) <= max_outliers, (k, len(bad))
+        assert row_err.max() <= 1e-3 * scale, (k, row_err.max(), scale)
+        for i in bad:                                             # each outlier must sit on a flagged pixel
+            reach = 1.25 * radii[i] + 2                            # alpha >= 1/255 reaches ~3.3 sigma at opacity ~1
+            near = (np.abs(fx - m2[i, 0]) <= reach) & (np.abs(fy - m2[i, 1]) <= reach)
+            assert near.any(), f"{k}: Gaussian {i} differs by {row_err[i] / scale:.2e} with no threshold-fragile pixel in its footprint"
+    return report
+
+
 def box_setup(P, W, H, seed=0, scale_mult=1.0, sh_coeffs=16):
     cam = cameras.identity_camera(W, H)
     cloud = synthetic.make_cloud(P, "box", seed, sh_coeffs=sh_coeffs, scale_mult=scale_mult)

@@ -137,8 +137,10 @@ def test_c2_full_size_parity(hip_device):
     ref = hp.run_oracle(cloud, cam, 3, bg, g)
     hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
     fig = hp.compare_forward(hip, ref)
-    gfig = hp.compare_grads(hip["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
-    print("C2", ref["num_rendered"], fig, {k: f"{e / s:.2e}" for k, (e, s) in gfig.items()})
+    # the same bar as C3 below: rows within 1e-4 of the tensor's maximum; a row beyond it must belong to a Gaussian with
+    # an oracle-flagged threshold pixel in its footprint (and stay within 1e-3)
+    report = hp.compare_grads_by_row(hip, ref, 100_000, max_outliers=4)
+    print("C2", ref["num_rendered"], fig, report)
 
 
 def test_c3_full_size_parity_one_view(hip_device):
@@ -156,23 +158,7 @@ def test_c3_full_size_parity_one_view(hip_device):
     ref = hp.run_oracle(cloud, cam, 3, bg, g)
     hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
     fig = hp.compare_forward(hip, ref)
-    st = ref["res"].stage()
-    fy, fx = np.nonzero(st["fragile"] != 0)
-    m2, radii = st["means2D"], ref["radii"]
-    report = {}
-    for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations"):
-        a = hip["grads"][k].reshape(1_000_000, -1)
-        b = ref["grads"][k].reshape(1_000_000, -1)
-        scale = float(np.abs(b).max())
-        row_err = np.abs(a - b).max(axis=1)
-        bad = np.nonzero(row_err > hp.GRAD_RTOL * scale)[0]
-        report[k] = (f"{row_err.max() / scale:.2e}", len(bad))
-        assert len(bad) <= 32, (k, len(bad))
-        assert row_err.max() <= 1e-3 * scale, (k, row_err.max(), scale)
-        for i in bad:                                             # each outlier must sit on a flagged pixel
-            reach = 1.25 * radii[i] + 2                            # alpha >= 1/255 reaches ~3.3 sigma at opacity ~1
-            near = (np.abs(fx - m2[i, 0]) <= reach) & (np.abs(fy - m2[i, 1]) <= reach)
-            assert near.any(), f"{k}: Gaussian {i} differs by {row_err[i] / scale:.2e} with no threshold-fragile pixel in its footprint"
+    report = hp.compare_grads_by_row(hip, ref, 1_000_000)
     print("C3", ref["num_rendered"], fig, report)
 
 
