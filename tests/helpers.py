@@ -135,10 +135,14 @@ def compare_grads_by_row(hip, ref, P, names=("means2D", "opacity", "means3D", "s
         report[k] = (f"{row_err.max() / scale:.2e}", len(bad))
         assert len(bad) <= max_outliers, (k, len(bad))
         assert row_err.max() <= 1e-3 * scale, (k, row_err.max(), scale)
-        for i in bad:                                             # each outlier must sit on a flagged pixel
-            reach = 1.25 * radii[i] + 2                            # alpha >= 1/255 reaches ~3.3 sigma at opacity ~1
-            near = (np.abs(fx - m2[i, 0]) <= reach) & (np.abs(fy - m2[i, 1]) <= reach)
-            assert near.any(), f"{k}: Gaussian {i} differs by {row_err[i] / scale:.2e} with no threshold-fragile pixel in its footprint"
+        for i in bad:
+            # each outlier must TOUCH a flagged pixel: its own alpha there reaches the 1/255 threshold (to within 10 %),
+            # i.e. the pixel lies inside the splat's actual support, not merely inside its bounding square
+            ca, cb, cc, op = st["conic_opacity"][i].astype(np.float64)
+            dx, dy = m2[i, 0] - fx.astype(np.float64), m2[i, 1] - fy.astype(np.float64)
+            power = -0.5 * (ca * dx * dx + cc * dy * dy) - cb * dx * dy
+            touches = (power <= 1e-6) & (op * np.exp(np.minimum(power, 0.0)) >= 0.9 / 255.0)
+            assert touches.any(), f"{k}: Gaussian {i} differs by {row_err[i] / scale:.2e} and touches no threshold-fragile pixel"
     return report
 
 
