@@ -22,7 +22,7 @@ COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe
 # per-file extra flags
 SOURCES = {
     # bit-exact projection / conic / radius vs the CPU oracle: no FMA contraction in this TU
-    "preprocess.hip": ["-ffp-contract=off"],
+    "preprocess.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "binning.hip": [],          # the generic radix sort (simple-knn's Morton order)
     "tilebin.hip": [],          # compaction, tile partition, per-tile sort
     # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
@@ -30,7 +30,8 @@ SOURCES = {
     "render_bwd.hip": ["-fno-slp-vectorize"],
     "gauss_bwd.hip": [],
     "knn.hip": [],
-    "loss.hip": [],
+    # the separable window sums are long fma chains: packed f32 costs two issue slots plus the moves that form the pairs
+    "loss.hip": ["-fno-slp-vectorize"],
     "rows.hip": [],
     "adam.hip": [],
     "api.hip": [],

@@ -533,8 +533,9 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
             // the photometric loss of this view against its target and dL/dcolor, on the same stream
             // (R/luciddreamer.py:301-304); out_losses[3 v .. 3 v + 2] = {loss, l1, ssim}
             float* gimg = reinterpret_cast<float*>(slot + SL.grad_img);
-            launch_loss_forward(3, height, width, color, targets[v], lambda_dssim, out_losses + 3 * (size_t)v, slot + SL.loss_ws, s);
-            launch_loss_backward(3, height, width, color, targets[v], lambda_dssim, nullptr, slot + SL.loss_ws, gimg, s);
+            launch_loss_forward(3, height, width, color, targets[v], lambda_dssim, out_losses + 3 * (size_t)v, slot + SL.loss_ws, s, true);
+            launch_loss_backward(3, height, width, color, targets[v], lambda_dssim, nullptr, slot + SL.loss_ws, gimg, s,
+                                 out_losses + 3 * (size_t)v);
             view_grad = gimg;
         }
         rc = backward_core(P, D, M, LR_NUM_RENDERED_ON_DEVICE, background, width, height, means3D, shs, colors_precomp,
