@@ -349,6 +349,14 @@ int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const 
  * num_rendered via *num_rendered (may be NULL); returns 0, LR_ERR_OVERFLOW or LR_ERR_PREFILTERED. */
 int lr_check(const char* geom_buffer, long long* num_rendered, void* stream);
 
+/* The same without blocking (async mode's deferred overflow check): lr_header_post enqueues, on `stream`, a copy of the
+ * first 8 header words {num_rendered, overflow, prefilter trap, capacity, P, num_sorted, num_instances, bin_bound} into
+ * pinned memory owned by the library and returns a ticket >= 0 (or a negative LR_ERR_*).  lr_header_poll(ticket, block,
+ * out8) returns 1 and fills out8 once the copy has completed (the ticket is then released), 0 if it has not and
+ * block == 0, a negative LR_ERR_* on a bad ticket.  The device current at lr_header_post must be the buffer's. */
+long long lr_header_post(const char* geom_buffer, void* stream);
+int lr_header_poll(long long ticket, int block, unsigned int* out8);
+
 /* Optional per-stage timing with HIP events recorded on the call's stream (bench.py roofline leg).
  * lr_profile_enable(1) clears and starts recording, (0) stops; returns the number of stages.
  * lr_profile_read waits for the recorded events and returns, per stage, the summed elapsed

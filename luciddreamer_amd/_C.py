@@ -88,3 +88,13 @@ def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, featur
 
 mark_visible = _C_ext.mark_visible
 check = _C_ext.check
+
+
+def header_post(geomBuffer):
+    """Non-blocking read-back of a forward's header on the current stream (lr_header_post); returns a ticket."""
+    return _C_ext.header_post(geomBuffer)
+
+
+def header_poll(ticket, block=False):
+    """None while the read-back is in flight (block=False), else the 8 header words (the ticket is released)."""
+    return _C_ext.header_poll(ticket, block)

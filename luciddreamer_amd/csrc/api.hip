@@ -755,6 +755,58 @@ int lr_check(const char* geom_buffer, long long* num_rendered, void* stream_)
     return 0;
 }
 
+namespace {
+struct HeaderTicket { hipEvent_t ev = nullptr; uint32_t* host = nullptr; bool busy = false; };
+std::mutex g_hdr_mu;
+std::vector<HeaderTicket> g_hdr_tickets;
+}  // namespace
+
+long long lr_header_post(const char* geom_buffer, void* stream_)
+{
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
+    if (!geom_buffer) return fail(LR_ERR_INVALID_ARG, "NULL geom buffer");
+    long long t = -1;
+    HeaderTicket h;
+    {
+        std::lock_guard<std::mutex> lock(g_hdr_mu);
+        for (size_t i = 0; i < g_hdr_tickets.size(); i++)
+            if (!g_hdr_tickets[i].busy) { t = (long long)i; break; }
+        if (t < 0) {
+            HeaderTicket n;
+            LR_HIP_CHECK(hipEventCreateWithFlags(&n.ev, hipEventDisableTiming));
+            LR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&n.host), 8 * sizeof(uint32_t), hipHostMallocDefault));
+            g_hdr_tickets.push_back(n);
+            t = (long long)g_hdr_tickets.size() - 1;
+        }
+        g_hdr_tickets[(size_t)t].busy = true;
+        h = g_hdr_tickets[(size_t)t];
+    }
+    LR_HIP_CHECK(hipMemcpyAsync(h.host, geom_buffer, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    LR_HIP_CHECK(hipEventRecord(h.ev, s));
+    return t;
+}
+
+int lr_header_poll(long long ticket, int block, unsigned int* out8)
+{
+    HeaderTicket h;
+    {
+        std::lock_guard<std::mutex> lock(g_hdr_mu);
+        if (ticket < 0 || (size_t)ticket >= g_hdr_tickets.size() || !g_hdr_tickets[(size_t)ticket].busy)
+            return fail(LR_ERR_INVALID_ARG, "lr_header_poll: unknown ticket");
+        h = g_hdr_tickets[(size_t)ticket];
+    }
+    if (block) LR_HIP_CHECK(hipEventSynchronize(h.ev));
+    else {
+        const hipError_t q = hipEventQuery(h.ev);
+        if (q == hipErrorNotReady) return 0;
+        LR_HIP_CHECK(q);
+    }
+    if (out8) for (int i = 0; i < 8; i++) out8[i] = h.host[i];
+    std::lock_guard<std::mutex> lock(g_hdr_mu);
+    g_hdr_tickets[(size_t)ticket].busy = false;
+    return 1;
+}
+
 int lr_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lock(g_prof_mu);

@@ -308,6 +308,30 @@ int64_t check(const at::Tensor& geomBuffer)
     return n;
 }
 
+// async mode's deferred check without torch objects on the way: ticket of a non-blocking header read-back on the
+// current stream, and its poll (None while the copy is in flight, else the 8 header words)
+int64_t header_post(const at::Tensor& geomBuffer)
+{
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(geomBuffer.device());
+    const long long t = lr_header_post(static_cast<const char*>(geomBuffer.data_ptr()),
+                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(geomBuffer.device().index()).stream());
+    if (t < 0) raise_for((int)t, "header_post");
+    return t;
+}
+
+py::object header_poll(int64_t ticket, bool block)
+{
+    unsigned int w[8];
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = lr_header_poll(ticket, block ? 1 : 0, w);
+    }
+    if (rc < 0) raise_for(rc, "header_poll");
+    if (rc == 0) return py::none();
+    return py::make_tuple(w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -319,5 +343,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
     m.def("mark_visible", &mark_visible);
     m.def("check", &check);
+    m.def("header_post", &header_post);
+    m.def("header_poll", &header_poll);
     m.def("version", [] { return std::string(lr_version()); });
 }
