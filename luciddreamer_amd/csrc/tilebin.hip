@@ -359,26 +359,42 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     }
 }
 
-// per bin: exclusive prefix over the active workgroups (in place), total -> bin_total.  Eight independent loads are in
-// flight per thread before the dependent adds / stores (a load-store-load chain over 90 rows cost 27 us, this ~3 us).
-__global__ void __launch_bounds__(256)
+// per bin: exclusive prefix over the active workgroups (in place), total -> bin_total.  A workgroup takes 16 bins; its
+// 256 threads are 16 bins x 16 groups of rows (= partition workgroups), so a thread loads at most 16 counts, all
+// independent, and the groups are joined through LDS: two memory round trips for the kernel instead of one per eight rows
+// of one thread walking a whole column (8.4 us at C3: 32 workgroups, twelve dependent rounds).  Lanes 0-15 of a quarter wave
+// touch 16 consecutive words of one row.
+constexpr int SCAN1_BINS = 16, SCAN1_GROUPS = 16, SCAN1_ROWS = PART_BLOCKS_MAX / SCAN1_GROUPS;
+__global__ void __launch_bounds__(SCAN1_BINS * SCAN1_GROUPS)
 k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict__ part_hist, uint32_t* __restrict__ bin_total)
 {
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= bins) return;
+    __shared__ uint32_t s_tot[SCAN1_GROUPS][SCAN1_BINS + 1];
+    const int bl = threadIdx.x & (SCAN1_BINS - 1), g = threadIdx.x / SCAN1_BINS;
+    const int bin = blockIdx.x * SCAN1_BINS + bl;
     const int nb = part_active_blocks(hdr->num_compact);
-    uint32_t run = 0;
-    for (int b0 = 0; b0 < nb; b0 += 8) {
-        uint32_t v[8];
+    const int per = (nb + SCAN1_GROUPS - 1) / SCAN1_GROUPS;            // rows per group (<= SCAN1_ROWS)
+    const int r0 = g * per;
+    uint32_t v[SCAN1_ROWS];
+    uint32_t sum = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = (b0 + i < nb) ? part_hist[(size_t)(b0 + i) * bins + bin] : 0u;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if (b0 + i < nb) part_hist[(size_t)(b0 + i) * bins + bin] = run;
-            run += v[i];
-        }
+    for (int i = 0; i < SCAN1_ROWS; i++) {
+        const bool on = i < per && r0 + i < nb && bin < bins;
+        v[i] = on ? part_hist[(size_t)(r0 + i) * bins + bin] : 0u;
     }
-    bin_total[bin] = run;
+#pragma unroll
+    for (int i = 0; i < SCAN1_ROWS; i++) sum += v[i];
+    s_tot[g][bl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < SCAN1_GROUPS; j++) { const uint32_t t = s_tot[j][bl]; if (j < g) run += t; total += t; }
+    if (bin >= bins) return;
+#pragma unroll
+    for (int i = 0; i < SCAN1_ROWS; i++) {
+        if (i < per && r0 + i < nb) part_hist[(size_t)(r0 + i) * bins + bin] = run;
+        run += v[i];
+    }
+    if (g == 0) bin_total[bin] = total;
 }
 
 // -------------------------------------------------------------------------------------------
@@ -647,7 +663,8 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                        vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words);
     if (t) t->mark(1, s);
-    hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + 255) / 256), dim3(256), 0, s, pp.bins, hdr, part_hist, bin_total);
+    hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
+                       part_hist, bin_total);
     if (t) t->mark(2, s);
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
