@@ -208,6 +208,35 @@ def test_async_mode_matches_exact(hip_device):
         _C.check(out[4])
 
 
+def test_header_tickets(hip_device):
+    """lr_header_post / lr_header_poll (the non-blocking read-back behind async mode's deferred check): the words are the
+    header's, a ticket is released by the poll that completes it, and a released or unknown ticket is an error."""
+    from luciddreamer_amd import _C
+    cam, cloud = hp.box_setup(8_000, 192, 128)
+    dev = hip_device
+    tfx, tfy = hp.tan_fov(cam)
+    camd = cam.to(dev)
+    args = (torch.zeros(3, device=dev), cloud["means3D"].to(dev), torch.Tensor([]), cloud["opacities"].to(dev),
+            cloud["scales"].to(dev), cloud["rotations"].to(dev), 1.0, torch.Tensor([]), camd.world_view_transform,
+            camd.full_proj_transform, tfx, tfy, 128, 192, cloud["shs"].to(dev), 3, camd.camera_center, False, False)
+    exact = _C.rasterize_gaussians(*args)
+    out = _C.rasterize_gaussians(*args, binning_capacity=10_000_000)
+    tickets = [_C.header_post(out[4]) for _ in range(3)]
+    assert len(set(tickets)) == 3
+    words = [_C.header_poll(t, True) for t in tickets]
+    assert words[0] == words[1] == words[2]
+    num_rendered, overflow, trap, capacity, P = words[0][:5]
+    assert num_rendered == exact[0] and overflow == 0 and trap == 0 and capacity == 10_000_000 and P == 8_000
+    assert words[0][6] <= num_rendered and words[0][5] == words[0][6]          # instances after exact culling, all sorted
+    with pytest.raises(RuntimeError, match="ticket"):
+        _C.header_poll(tickets[0], False)                                       # released by the poll above
+    with pytest.raises(RuntimeError, match="ticket"):
+        _C.header_poll(1 << 40, False)
+    assert _C.header_post(out[4]) in tickets                                    # released tickets are handed out again
+    small = _C.rasterize_gaussians(*args, binning_capacity=100)
+    assert _C.header_poll(_C.header_post(small[4]), True)[1] == 1               # overflow flag
+
+
 def test_async_mode_warm_calls_and_overflow_policy(hip_device):
     """warm_calls exact forwards feed the high-water mark; a deferred overflow raises by default and only warns with
     on_overflow="warn" (the capacity is raised either way and later views are complete again)."""
