@@ -89,6 +89,7 @@ constexpr int TSORT_THREADS = 512;          // threads of the bucket-sort class
 constexpr int TSORT_MID_LDS = 4096;         // ... its bin entries (32 KB of words + 16 KB of bucket counters)
 constexpr int TSORT_BIG_LDS = 16384;        // ... the large-bin kernel (128 KB); beyond: in place in global memory
 constexpr int TSORT_BIG_BLOCKS = 256;
+constexpr int TSORT_CLASS_BLOCKS = 2048;     // grid cap of the 257..768 and 769..4096 classes (grid-stride over the bins)
 struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)
 PartPlan part_plan(int num_tiles);
 

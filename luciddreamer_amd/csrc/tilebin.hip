@@ -469,19 +469,21 @@ k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_
 // these sizes its ~45 cheap stages beat the bucket sort's scan and two atomic passes (dense 1 M cloud at 1080p: 0.087 vs
 // 0.152 ms per view), and the small footprint keeps many bins resident per CU.
 __global__ void __launch_bounds__(256)
-k_tile_sort_net(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+k_tile_sort_net(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
                 const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
                 uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
     __shared__ unsigned long long s_a[TSORT_NET_LDS];
-    const int bin = (int)blockIdx.x;
-    const uint32_t n = bin_total[bin];
-    if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_NET_LDS) return;
-    const uint32_t start = bin_start[bin];
-    for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
-    __syncthreads();
-    bitonic_sort(s_a, n, threadIdx.x, 256u, [] { __syncthreads(); });
-    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
+    for (int bin = (int)blockIdx.x; bin < bins; bin += (int)gridDim.x) {          // grid: see launch_tile_binning
+        const uint32_t n = bin_total[bin];
+        if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_NET_LDS) continue;
+        const uint32_t start = bin_start[bin];
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
+        __syncthreads();
+        bitonic_sort(s_a, n, threadIdx.x, 256u, [] { __syncthreads(); });
+        write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
+    }
 }
 
 // 769..4096 entries: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
@@ -492,7 +494,7 @@ k_tile_sort_net(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
 // falls back to the bitonic network.  ~8 barriers instead of the network's 66 at these sizes (dense 512^2 view: 0.145 ->
 // 0.052 ms).
 __global__ void __launch_bounds__(TSORT_THREADS)
-k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+k_tile_sort_mid(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
                 const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
                 uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
@@ -502,11 +504,12 @@ k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
     __shared__ unsigned long long s_red[2 * (TSORT_THREADS / 64)];
     __shared__ uint32_t s_wave[TSORT_THREADS / 64];
     __shared__ uint32_t s_bad;
-    const int bin = (int)blockIdx.x;
-    const uint32_t n = bin_total[bin];
-    if (n <= (uint32_t)TSORT_NET_LDS || n > (uint32_t)TSORT_MID_LDS) return;
-    const uint32_t start = bin_start[bin];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int bin = (int)blockIdx.x; bin < bins; bin += (int)gridDim.x) {          // grid: see launch_tile_binning
+    const uint32_t n = bin_total[bin];
+    if (n <= (uint32_t)TSORT_NET_LDS || n > (uint32_t)TSORT_MID_LDS) continue;
+    const uint32_t start = bin_start[bin];
+    __syncthreads();
     unsigned long long item[PER];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
@@ -584,6 +587,7 @@ k_tile_sort_mid(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __r
         __syncthreads();
     }
     write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+    }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -672,9 +676,14 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (t) t->mark(3, s);
     hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(64), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges);
-    hipLaunchKernelGGL(k_tile_sort_net, dim3(pp.bins), dim3(256), 0, s, pp.sub_shift, slot_bits, num_tiles,
+    // the two middle classes walk the bins with a capped grid: a launch that finds nothing in its size class -- every view of
+    // a sparse scene -- then costs 2048 workgroups instead of one per bin (beside a blend kernel that fills the CUs, 8160
+    // workgroups of 48 KB of LDS each took 34 us to be handed out and retire); +1.1 % on the three-stream C3 headline, +0.7
+    // to 1.6 % on the dense shapes, where 2048 is still more than fit on the chip at once
+    const int class_blocks = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;
+    hipLaunchKernelGGL(k_tile_sort_net, dim3(class_blocks), dim3(256), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges);
-    hipLaunchKernelGGL(k_tile_sort_mid, dim3(pp.bins), dim3(TSORT_THREADS), 0, s, pp.sub_shift, slot_bits, num_tiles,
+    hipLaunchKernelGGL(k_tile_sort_mid, dim3(class_blocks), dim3(TSORT_THREADS), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
                        bin_start, bin_total, words, point_list, ranges);
     hipLaunchKernelGGL(k_tile_sort_big, dim3(TSORT_BIG_BLOCKS), dim3(1024), (size_t)TSORT_BIG_LDS * 8, s, pp.sub_shift, slot_bits,
                        num_tiles, bin_start, bin_total, words, point_list, ranges, big_queue);
