@@ -512,7 +512,6 @@ static int views_core(int n_views, const float* const* viewmatrices, const float
     if (acc_scale) mask |= LR_ACC_SCALE;
     if (acc_rot) mask |= LR_ACC_ROT;
 
-    struct CorunScope { CorunScope(bool on) { set_blend_corun(on); } ~CorunScope() { set_blend_corun(false); } } corun(n_streams > 1);
     hipEvent_t prev = nullptr;
     for (int v = 0; v < n_views; v++) {
         const int si = v % n_streams;

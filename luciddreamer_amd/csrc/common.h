@@ -290,8 +290,6 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
     }
     return t < num_tiles ? t : -1;
 }
-// hint from the multi-stream view loop (api.hip views_core) to the blend backward launcher: other kernels run beside it
-void set_blend_corun(bool on);
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s);

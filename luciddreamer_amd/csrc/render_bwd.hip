@@ -331,9 +331,6 @@ int blend_tile_map(int num_tiles)
     return num_tiles <= 4096 ? TILE_MAP_PLAIN : TILE_MAP_BANDS;
 }
 
-static thread_local bool g_blend_corun = false;
-void set_blend_corun(bool on) { g_blend_corun = on; }
-
 bool blend_quad(int num_tiles)
 {
     static const int forced = [] { const char* e = getenv("LR_BLEND_QUAD_BWD"); return e ? atoi(e) : -1; }();
@@ -355,12 +352,12 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    // Co-run hint (set by the multi-stream view loop): when kernels of other views run beside this one, 8 KB of unused
-    // dynamic LDS cap it at 5 waves per SIMD instead of 7.  Alone it is then 11 % slower (0.102 -> 0.114 ms on C3), but
-    // the slots it leaves let the HBM-bound kernels of the other streams (preprocess, per-Gaussian backward, sorts) run
-    // under its VALU-bound loop: C3 with 3 streams 3985 -> 4150 views/s.  LR_BWD_LDS_PAD=<bytes> overrides (diagnostics).
+    // LR_BWD_LDS_PAD=<bytes> of unused dynamic LDS lowers the occupancy of the 2-wave shape (diagnostics).  Round 1 ran it
+    // with 8 KB (5 waves per SIMD instead of 7) inside the multi-stream view loop, which then gained 3 % because the other
+    // streams' memory-bound kernels found room beside it; with round 2's binning that no longer holds: alternated on one box,
+    // no pad wins everywhere (C3 +0.8 %, C2 +4.3 %, dense box +1.8 %, C4 shape +2.8 %, fused-loss step +1.4 %).
     static const int forced_pad = [] { const char* e = getenv("LR_BWD_LDS_PAD"); return e ? atoi(e) : -1; }();
-    const int pad = forced_pad >= 0 ? forced_pad : (g_blend_corun ? 8192 : 0);
+    const int pad = forced_pad >= 0 ? forced_pad : 0;
     if (blend_quad(num_tiles))
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
                            final_T, n_contrib, dL_dpix, bin_base, hdr);

@@ -10,7 +10,7 @@ print('$name', d['value'], 'host', d['config']['host_issue_ms_per_step'], {k:v f
 EXTRA="" one base X=1
 EXTRA="--streams 2" one streams2 X=1
 EXTRA="--streams 4" one streams4 X=1
-EXTRA="" one pad0 LR_BWD_LDS_PAD=0
+EXTRA="" one pad8k LR_BWD_LDS_PAD=8192
 EXTRA="" one pad16k LR_BWD_LDS_PAD=16384
 EXTRA="--workload c3box" one c3box X=1
 EXTRA="--workload c4shape" one c4shape X=1
