@@ -1,0 +1,129 @@
+"""CPU: the host logic of async mode (luciddreamer_amd.config) -- high-water mark, warm calls, the deferred overflow
+check over header tickets and its two policies -- with the binding's two ticket functions replaced by a fake that
+completes read-backs on demand.  The real lr_header_post / lr_header_poll are exercised on the GPU
+(tests/test_gpu_parity.py::test_header_tickets)."""
+import types
+import warnings
+
+import pytest
+import torch
+
+from luciddreamer_amd import config
+
+
+class FakeBinding:
+    """header_post hands out tickets; header_poll returns None until `complete()` was called for the ticket."""
+
+    def __init__(self):
+        self.next, self.words, self.done, self.polled = 0, {}, set(), []
+
+    def header_post(self, geom):
+        t = self.next
+        self.next += 1
+        self.words[t] = tuple(int(v) for v in geom)
+        return t
+
+    def header_poll(self, ticket, block=False):
+        self.polled.append((ticket, block))
+        if not block and ticket not in self.done:
+            return None
+        return self.words.pop(ticket)
+
+    def complete(self, *tickets):
+        self.done.update(tickets)
+
+
+@pytest.fixture
+def fake(monkeypatch):
+    import luciddreamer_amd
+    f = FakeBinding()
+    monkeypatch.setitem(__import__("sys").modules, "luciddreamer_amd._C", f)
+    monkeypatch.setattr(luciddreamer_amd, "_C", f, raising=False)
+    config.set_async(False)
+    config.reset()
+    yield f
+    config._pending.clear()
+    config.set_async(False)
+    config._hwm.clear()
+    config._seen.clear()
+
+
+def _rs(h=64, w=96):
+    return types.SimpleNamespace(image_height=h, image_width=w)
+
+
+def _header(num_rendered, overflow=0, trap=0, instances=None):
+    inst = num_rendered if instances is None else instances
+    return [num_rendered, overflow, trap, 0, 0, inst, inst, 0]
+
+
+def test_exact_until_a_mark_exists_then_capacity_from_the_mark(fake):
+    means = torch.zeros(1000, 3)
+    rs = _rs()
+    assert config.capacity_for(means, rs) == 0                      # async off: always exact
+    config.set_async(True, headroom=1.5)
+    assert config.capacity_for(means, rs) == 0                      # first sighting: measured exactly
+    config.note_forward(means, rs, 10_000, None, 0)                 # an exact forward feeds the mark directly, no ticket
+    assert fake.next == 0
+    cap = config.capacity_for(means, rs)
+    assert cap == int(10_000 * 1.5) + 4096
+    assert config.capacity_for(torch.zeros(0, 3), rs) == 0          # empty cloud: nothing to size
+    assert config.capacity_for(torch.zeros(1000, 3), _rs(32, 32)) == 0      # another (P, H, W): its own first sighting
+
+
+def test_deferred_check_polls_in_order_and_raises_the_mark(fake):
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, headroom=1.2)
+    config.note_forward(means, rs, 5_000, None, 0)
+    cap = config.capacity_for(means, rs)
+    config.note_forward(means, rs, -1, _header(7_000, instances=6_500), cap)    # async forward: a ticket, nothing blocks
+    config.note_forward(means, rs, -1, _header(6_000, instances=5_500), cap)
+    assert fake.next == 2 and len(config._pending) == 2
+    config.capacity_for(means, rs)                                   # polls: nothing has completed
+    assert len(config._pending) == 2
+    fake.complete(1)                                                 # out of order: the queue waits for ticket 0
+    config.capacity_for(means, rs)
+    assert len(config._pending) == 2
+    fake.complete(0)
+    assert config.capacity_for(means, rs) == int(6_500 * 1.2) + 4096          # the mark follows the instances actually emitted
+    assert not config._pending
+
+
+def test_overflow_policies(fake):
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, headroom=1.0)
+    config.note_forward(means, rs, 1_000, None, 0)
+    cap = config.capacity_for(means, rs)
+    config.note_forward(means, rs, -1, _header(50_000, overflow=1), cap)
+    with pytest.raises(RuntimeError, match="capacity"):
+        config.drain()                                               # blocks on the ticket, then raises (default policy)
+    assert fake.polled[-1] == (0, True)
+    assert config.capacity_for(means, rs) == 50_000 + 4096            # raised from the true count either way
+    config.set_async(True, headroom=1.0, on_overflow="warn")
+    config.note_forward(means, rs, -1, _header(80_000, overflow=1), cap)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        config.drain()
+    assert any("binning capacity" in str(x.message) for x in w)
+    config.note_forward(means, rs, -1, _header(10, trap=1), cap)
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        config.drain()
+    with pytest.raises(ValueError):
+        config.set_async(True, on_overflow="ignore")
+
+
+def test_check_every_samples_and_warm_calls_stay_exact(fake):
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, check_every=3, warm_calls=2)
+    assert config.capacity_for(means, rs) == 0
+    config.note_forward(means, rs, 1_000, None, 0)
+    assert config.capacity_for(means, rs) == 0                       # second warm call: still exact
+    config.note_forward(means, rs, 2_000, None, 0)
+    cap = config.capacity_for(means, rs)
+    assert cap == int(2_000 * 1.3) + 4096
+    base = config._calls
+    for _ in range(6):
+        config.note_forward(means, rs, -1, _header(1_500), cap)
+    assert fake.next == (base + 6) // 3 - base // 3                  # every third async forward posts a ticket
+    fake.complete(*range(fake.next))
+    config.drain()
