@@ -362,6 +362,11 @@ int lr_header_poll(long long ticket, int block, unsigned int* out8);
  * lr_profile_read waits for the recorded events and returns, per stage, the summed elapsed
  * milliseconds and the number of recorded calls.  Stage names: lr_profile_stage_name(i).
  * The stages "preprocess", "render_fwd", "render_bwd", "gauss_bwd" are exactly one kernel launch each. */
+/* Diagnostics: switch a kernel variant at run time (benchmark tooling measures two variants alternately in one process).
+ * Knobs: "bwd_red" (reduction variant of the blend backward), "blend_quad", "tile_map", "preprocess", "gauss_bwd", "tsort";
+ * value -1 restores the library's own rule.  Results are identical up to float summation order whatever the setting.
+ * Not part of the reference interface (it has no equivalent). */
+int lr_tune_set(const char* name, int value);
 int lr_profile_enable(int on);
 const char* lr_profile_stage_name(int stage);
 int lr_profile_read(double* ms_per_stage, long long* calls_per_stage, int n_stages);

@@ -26,7 +26,7 @@ _lock = threading.Lock()
 
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
            "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
-           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read",
+           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read", "lr_tune_set",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward",
            "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats",
@@ -130,6 +130,8 @@ def lib():
         L.lr_adam_step.restype = ci
         cd = ctypes.c_double
         L.lr_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, vp, cd, cd, cd, ci, vp]
+        L.lr_tune_set.restype = ci
+        L.lr_tune_set.argtypes = [ctypes.c_char_p, ci]
         L.lr_profile_enable.restype = ci
         L.lr_profile_enable.argtypes = [ci]
         L.lr_profile_stage_name.restype = ctypes.c_char_p
@@ -138,6 +140,13 @@ def lib():
         L.lr_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ll), ci]
         _lib = L
     return _lib
+
+
+def tune_set(name, value):
+    """Diagnostics: switch a kernel variant at run time (lr_tune_set); value -1 restores the library's own rule."""
+    rc = lib().lr_tune_set(name.encode(), int(value))
+    if rc < 0:
+        raise RuntimeError(last_error())
 
 
 def profile_enable(on=True):

@@ -91,6 +91,9 @@ struct BinProf : lr::TileBinTimes {
     }
 };
 
+int g_tune[lr::TUNE_COUNT] = { -1, -1, -1, -1, -1, -1 };
+const char* const kTuneNames[lr::TUNE_COUNT] = { "bwd_red", "blend_quad", "tile_map", "preprocess", "gauss_bwd", "tsort" };
+
 int bits_for(uint32_t max_value)
 {
     int b = 0;
@@ -99,6 +102,10 @@ int bits_for(uint32_t max_value)
 }
 
 }  // namespace
+
+namespace lr {
+int tune_get(int key) { return (key >= 0 && key < TUNE_COUNT) ? g_tune[key] : -1; }
+}  // namespace lr
 
 extern "C" {
 
@@ -199,6 +206,10 @@ static int forward_core(lr_alloc_fn geom_alloc, void* geom_user, lr_alloc_fn bin
             LR_HIP_CHECK(hipMemcpyAsync(meta, hdr, sizeof(meta), hipMemcpyDeviceToHost, s));
             LR_HIP_CHECK(hipStreamSynchronize(s));
             R_bound = meta[6];
+            // the return value is the reference's `int num_rendered` (rasterizer_impl.cu:281); negative values are error
+            // codes here, so a count that does not fit is an explicit error instead of a wrapped-around one
+            if (meta[0] > 0x7FFFFFFFu)
+                return fail(LR_ERR_INVALID_ARG, "num_rendered exceeds INT_MAX: use async mode (binning_capacity > 0) and read the count with lr_check");
             num_rendered = (int)meta[0];
         } else {
             R_bound = binning_capacity;
@@ -755,33 +766,48 @@ int lr_check(const char* geom_buffer, long long* num_rendered, void* stream_)
 }
 
 namespace {
-struct HeaderTicket { hipEvent_t ev = nullptr; uint32_t* host = nullptr; bool busy = false; };
+// A ticket's event belongs to the device that was current when it was created: tickets are only ever re-used on that
+// device (one process may drive several devices; recording an event on another device's stream is an error).
+struct HeaderTicket { hipEvent_t ev = nullptr; uint32_t* host = nullptr; bool busy = false; int device = -1; };
 std::mutex g_hdr_mu;
 std::vector<HeaderTicket> g_hdr_tickets;
+void header_ticket_release(long long t)
+{
+    std::lock_guard<std::mutex> lock(g_hdr_mu);
+    if (t >= 0 && (size_t)t < g_hdr_tickets.size()) g_hdr_tickets[(size_t)t].busy = false;
+}
 }  // namespace
 
 long long lr_header_post(const char* geom_buffer, void* stream_)
 {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream_);
     if (!geom_buffer) return fail(LR_ERR_INVALID_ARG, "NULL geom buffer");
+    int device = 0;
+    LR_HIP_CHECK(hipGetDevice(&device));
     long long t = -1;
     HeaderTicket h;
     {
         std::lock_guard<std::mutex> lock(g_hdr_mu);
         for (size_t i = 0; i < g_hdr_tickets.size(); i++)
-            if (!g_hdr_tickets[i].busy) { t = (long long)i; break; }
+            if (!g_hdr_tickets[i].busy && g_hdr_tickets[i].device == device) { t = (long long)i; break; }
         if (t < 0) {
             HeaderTicket n;
+            n.device = device;
             LR_HIP_CHECK(hipEventCreateWithFlags(&n.ev, hipEventDisableTiming));
-            LR_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&n.host), 8 * sizeof(uint32_t), hipHostMallocDefault));
+            const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&n.host), 8 * sizeof(uint32_t), hipHostMallocDefault);
+            if (e != hipSuccess) { (void)hipEventDestroy(n.ev); return fail(LR_ERR_HIP, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
             g_hdr_tickets.push_back(n);
             t = (long long)g_hdr_tickets.size() - 1;
         }
         g_hdr_tickets[(size_t)t].busy = true;
         h = g_hdr_tickets[(size_t)t];
     }
-    LR_HIP_CHECK(hipMemcpyAsync(h.host, geom_buffer, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    LR_HIP_CHECK(hipEventRecord(h.ev, s));
+    hipError_t e = hipMemcpyAsync(h.host, geom_buffer, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipEventRecord(h.ev, s);
+    if (e != hipSuccess) {                                   // the ticket must not stay busy for ever
+        header_ticket_release(t);
+        return fail(LR_ERR_HIP, std::string("lr_header_post: ") + hipGetErrorString(e));
+    }
     return t;
 }
 
@@ -794,16 +820,23 @@ int lr_header_poll(long long ticket, int block, unsigned int* out8)
             return fail(LR_ERR_INVALID_ARG, "lr_header_poll: unknown ticket");
         h = g_hdr_tickets[(size_t)ticket];
     }
-    if (block) LR_HIP_CHECK(hipEventSynchronize(h.ev));
-    else {
-        const hipError_t q = hipEventQuery(h.ev);
-        if (q == hipErrorNotReady) return 0;
-        LR_HIP_CHECK(q);
+    hipError_t q = block ? hipEventSynchronize(h.ev) : hipEventQuery(h.ev);
+    if (q == hipErrorNotReady) return 0;
+    if (q != hipSuccess) {
+        header_ticket_release(ticket);
+        return fail(LR_ERR_HIP, std::string("lr_header_poll: ") + hipGetErrorString(q));
     }
     if (out8) for (int i = 0; i < 8; i++) out8[i] = h.host[i];
-    std::lock_guard<std::mutex> lock(g_hdr_mu);
-    g_hdr_tickets[(size_t)ticket].busy = false;
+    header_ticket_release(ticket);
     return 1;
+}
+
+int lr_tune_set(const char* name, int value)
+{
+    if (!name) return fail(LR_ERR_INVALID_ARG, "lr_tune_set: NULL name");
+    for (int i = 0; i < lr::TUNE_COUNT; i++)
+        if (std::strcmp(name, kTuneNames[i]) == 0) { g_tune[i] = value; return 0; }
+    return fail(LR_ERR_INVALID_ARG, std::string("lr_tune_set: unknown knob ") + name);
 }
 
 int lr_profile_enable(int on)

@@ -267,6 +267,11 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
                         TileBinTimes* t, hipStream_t s);
 
+// Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
+// are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_COUNT };
+int tune_get(int key);
+
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per
 // tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue
 // bound).  LR_BLEND_QUAD_BWD=0/1 forces one (diagnostics).

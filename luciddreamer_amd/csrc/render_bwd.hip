@@ -12,10 +12,11 @@
 //   * the nine per-(pixel,Gaussian) gradient terms reach memory as
 //       reference: 9 global float atomicAdd per contributing pixel x Gaussian pair (:537-583)
 //       here:      wave64 reduction of 8 terms with v_permlane32_swap / v_permlane16_swap (each swap+add
-//                  halves TWO terms at once, all six swaps in one asm block) + 4 DPP steps inside the 16-lane
-//                  rows = 20 instructions (a per-term DPP tree costs 48 + hazard nops), 9th term by DPP;
-//                  -> 3 LDS float-add instructions per wave (4 lanes each, one address register) into a per-batch
-//                     accumulator
+//                  halves TWO terms at once, all six swaps in one asm block) down to 16-lane rows, then 7 DPP adds
+//                  that keep the terms TRANSPOSED inside the rows (row_merge3: a DPP add under a bank mask hands
+//                  half of the lanes to another term at every level) instead of three row sums of 4 DPP adds each;
+//                  -> ONE plain 12-lane ds_write into the wave's own copy of the per-batch accumulator (round 2:
+//                     three LDS float atomics -- ds_add_f32 retires ~3 cycles per active lane on MI355X)
 //                  -> ONE plain 48-byte store per tile instance into that instance's own slot
 //                     (inst_grad[emission index]); the slots of a Gaussian are contiguous and are summed,
 //                     in a fixed order, by k_gauss_bwd.  No global atomics at all, nothing to pre-zero.
@@ -72,6 +73,33 @@ __device__ __forceinline__ void reduce8(float& a0, float a1, float a2, float a3,
                  "v_add_f32 %0, %0, %2\n\t"
                  "v_add_f32 %4, %4, %6"
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
+}
+// Finish the wave reduction inside the 16-lane rows with the terms kept TRANSPOSED: instead of three independent row sums
+// (4 DPP adds each: every level adds a register to a shifted copy of itself and all sixteen lanes end up with the same
+// total), each level hands one half of the lanes to another term -- a DPP add under a bank mask writes only the lanes it
+// is enabled for, so `x[0..7] = a[l] + a[l+8]` and `x[8..15] = b[l] + b[l-8]` are two instructions that leave ONE register
+// to carry on with.  In: ra / rb = the row partials reduce8 left (one term per row each), sB = the lane's raw db term.
+// Out: lane 0 of each row = that row's `ra` term, lane 8 = its `rb` term, lane 4 = the row's partial of db.
+// 7 DPP adds instead of 12, and the three accumulator updates become one.  Wait states by hand (inline asm is opaque to
+// the hazard recogniser): a DPP source written by a VALU instruction needs two other instructions or nops in between.
+// (All DPP controls cost the same here -- 4.3 to 4.9 cycles per wave64 add against 2.8 for a plain one,
+// tools/valu_microbench.hip -- so only the COUNT matters: row sums by rotation instead of the compiler's quad_perm /
+// row_mirror idiom measured no different, profiles/r03b_ab_bwd_red_dpp_store.json.)
+__device__ __forceinline__ float row_merge3(float ra, float rb, float sB)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"        // db: l + (l ^ 8)
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"        // lanes 8-15: rb[l] + rb[l-8]
+                 "v_add_f32_dpp %1, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"        // lanes 0-7:  ra[l] + ra[l+8]
+                 "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"        // lanes 4-7, 12-15: db[l] + db[l-4]
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %2, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"        // lanes 0-3, 8-11: m[l] + m[l+4]
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+                 : "+v"(ra), "+v"(rb), "+v"(sB));
+    return sB;
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 {
@@ -142,8 +170,12 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     }
 }
 
+// MERGE: row_merge3 + one plain store per candidate into the wave's own accumulator copy (the default); false = the round-2
+// reduction (three row sums, three LDS float atomics into a shared copy), kept selectable for A/B runs (tools/ab_bench.py).
+// Measured on MI355X, k_render_bwd single stream (profiles/r03b_ab_bwd_red_dpp_store.json): C3 100.6 -> 94.2 us, dense
+// 1 M cloud 526 -> 485 us, C5 shape (QUAD) 362 -> 324 us.
 // 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
-template <bool QUAD>
+template <bool QUAD, bool MERGE>
 __global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 4 : 7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
@@ -157,13 +189,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
-    // per-batch gradient accumulator, columns below.  2-wave shape: both waves add into the same entry -- two operands,
-    // so the float sum does not depend on which wave comes first.  QUAD shape: four waves would make it depend on the
-    // arrival order (run-to-run different bits), so every wave adds into its OWN copy and the flush sums the four copies
-    // in a fixed order: the backward is bit-repeatable at every image size.
-    constexpr int NACC = QUAD ? 4 : 1;
-    __shared__ float s_acc[BATCH][NACC][12];
+    // per-batch gradient accumulator, columns below.  Every wave owns a copy: a wave meets a staged candidate at most once
+    // per batch, so its contribution is a plain store (nothing is ever added twice to one word), and the flush sums the
+    // copies in a fixed order: the backward is bit-repeatable at every image size.  (!MERGE, 2-wave shape: both waves add
+    // into ONE copy with LDS float atomics -- two operands, so the sum does not depend on which wave comes first.)
     constexpr int NWAVES = QUAD ? 4 : 2;
+    constexpr int NACC = (QUAD || MERGE) ? NWAVES : 1;
+    __shared__ float s_acc[BATCH][NACC][12];
     __shared__ uint32_t s_wlast[NWAVES];
 
     const int tile = blend_tile(tile_map, num_tiles);
@@ -214,6 +246,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // reduce8 a: (dmx, dmy, dca, dcb)
                                                                                 // reduce8 b: (dcc, dop, dr, dg) at col_a + 4
     const bool row_leader = (l & 15) == 0;
+    // MERGE: lanes 0 / 8 / 4 of every row end up with the row's a term, b term and db partial (row_merge3)
+    const int l16 = l & 15;
+    const bool merge_writer = (l16 & 3) == 0 && l16 < 12;
+    const uint32_t merge_off = (uint32_t)(w * 12 + (l16 == 0 ? col_a : l16 == 8 ? col_a + 4 : 8 + row));
 
     for (int base = 0; base < total; base += BATCH) {
         // staged element i <-> list position pos = total-1-base-i (back to front)
@@ -283,17 +319,22 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float sMyy = dys * sMy;
                 float ra = sMx, rb = sMyy;
                 reduce8(ra, sMy, sMxx, sMxy, rb, sD, sR, sG);
-                ra = row_sum(ra); rb = row_sum(rb);
-                float rc = row_sum(sB);                           // every row: its partial of db
-                // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
-                // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
-                asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
-                // one address per lane: columns col_a, col_a + 4, col_a + 8 (the db partial of each row has its own column)
-                float* dst = s_acc[j][QUAD ? w : 0] + col_a;
-                if (row_leader) {
-                    atomicAdd(dst, ra);
-                    atomicAdd(dst + 4, rb);
-                    atomicAdd(dst + 8, rc);
+                if (MERGE) {
+                    const float rc = row_merge3(ra, rb, sB);
+                    if (merge_writer) (&s_acc[0][0][0])[(uint32_t)j * (12u * NACC) + merge_off] = rc;
+                } else {
+                    ra = row_sum(ra); rb = row_sum(rb);
+                    float rc = row_sum(sB);                           // every row: its partial of db
+                    // keep the last DPP add of each row sum in front of the leader branch (otherwise the compiler sinks the
+                    // add into the branch and leaves a v_mov_dpp + v_mov 0 pair behind: 3 instructions instead of 1)
+                    asm volatile("" : "+v"(ra), "+v"(rb), "+v"(rc));
+                    // one address per lane: columns col_a, col_a + 4, col_a + 8 (the db partial of each row has its own column)
+                    float* dst = s_acc[j][QUAD ? w : 0] + col_a;
+                    if (row_leader) {
+                        atomicAdd(dst, ra);
+                        atomicAdd(dst + 4, rb);
+                        atomicAdd(dst + 8, rc);
+                    }
                 }
             }
         }
@@ -327,6 +368,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 int blend_tile_map(int num_tiles)
 {
     static const int forced = [] { const char* e = getenv("LR_TILE_MAP"); return e ? atoi(e) : -1; }();
+    if (tune_get(TUNE_TILE_MAP) >= 0) return tune_get(TUNE_TILE_MAP);
     if (forced >= 0) return forced;
     return num_tiles <= 4096 ? TILE_MAP_PLAIN : TILE_MAP_BANDS;
 }
@@ -334,6 +376,7 @@ int blend_tile_map(int num_tiles)
 bool blend_quad(int num_tiles)
 {
     static const int forced = [] { const char* e = getenv("LR_BLEND_QUAD_BWD"); return e ? atoi(e) : -1; }();
+    if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD) != 0;
     if (forced >= 0) return forced != 0;
     // The backward blend pays its cross-lane reduction per wave and candidate, so the 2-wave shape (a wave owns two
     // quadrants and reduces once for both) wins once 2 waves per tile come near filling the 1024 SIMDs x 7 wave slots;
@@ -358,12 +401,19 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     // no pad wins everywhere (C3 +0.8 %, C2 +4.3 %, dense box +1.8 %, C4 shape +2.8 %, fused-loss step +1.4 %).
     static const int forced_pad = [] { const char* e = getenv("LR_BWD_LDS_PAD"); return e ? atoi(e) : -1; }();
     const int pad = forced_pad >= 0 ? forced_pad : 0;
-    if (blend_quad(num_tiles))
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(grid), dim3(256), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, bin_base, hdr);
-    else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(grid), dim3(128), pad, s, W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg,
-                           final_T, n_contrib, dL_dpix, bin_base, hdr);
+    // lr_tune_set("bwd_red", 0) / LR_BWD_RED=0 selects the round-2 reduction (diagnostics, A/B runs)
+    static const int forced_red = [] { const char* e = getenv("LR_BWD_RED"); return e ? atoi(e) : -1; }();
+    const int red = tune_get(TUNE_BWD_RED) >= 0 ? tune_get(TUNE_BWD_RED) : forced_red;
+    const bool merge = red != 0;
+#define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr
+    if (blend_quad(num_tiles)) {
+        if (merge) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
+    } else {
+        if (merge) hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
+    }
+#undef LR_BWD_ARGS
 }
 
 }  // namespace lr

@@ -32,6 +32,7 @@
 //
 // 9 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
 // atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
+#include <mutex>
 #include "common.h"
 
 namespace lr {
@@ -642,17 +643,25 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
                         TileBinTimes* t, hipStream_t s)
 {
-    static bool attr_done = false;
-    if (!attr_done) {
-        // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort 128 KB
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                TSORT_BIG_LDS * 8) != hipSuccess)
-            return -1;
-        attr_done = true;
+    // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort 128 KB.  The attribute is
+    // set once per DEVICE (a process may drive several; runtimes that keep it per device would otherwise refuse the
+    // > 64 KB launches on the second one)
+    {
+        static std::mutex mu;
+        static bool attr_done[64] = {};
+        int device = 0;
+        if (hipGetDevice(&device) != hipSuccess) return -1;
+        std::lock_guard<std::mutex> lock(mu);
+        if (device < 0 || device >= 64 || !attr_done[device]) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    TSORT_BIG_LDS * 8) != hipSuccess)
+                return -1;
+            if (device >= 0 && device < 64) attr_done[device] = true;
+        }
     }
     const int num_tiles = gx * gy;
     const PartPlan pp = part_plan(num_tiles);
@@ -688,7 +697,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     hipLaunchKernelGGL(k_tile_sort_big, dim3(TSORT_BIG_BLOCKS), dim3(1024), (size_t)TSORT_BIG_LDS * 8, s, pp.sub_shift, slot_bits,
                        num_tiles, bin_start, bin_total, words, point_list, ranges, big_queue);
     if (t) t->mark(4, s);
-    return 0;
+    return hipGetLastError() == hipSuccess ? 0 : -1;        // a refused launch (LDS attribute, grid) surfaces here, not at the blend
 }
 
 }  // namespace lr

@@ -296,7 +296,7 @@ class ViewBatch:
         """acc: {"means3D", "means2D", "opacity", "sh", "scales", "rotations"} -> contiguous float32 tensors that are
         accumulated into (e.g. the .grad views of a FlatGrads bucket)."""
         P, M = int(means3D.shape[0]), int(shs.shape[1])
-        key = (P, self.capacity)
+        key = (P, self.capacity, self.n_streams)      # the workspace is sized per stream slot: set_streams() re-allocates
         if self._ws_key != key:
             size_fn = self.L.lr_views_train_workspace_bytes if self.train else self.L.lr_views_workspace_bytes
             nbytes = size_fn(P, self.W, self.H, self.capacity, self.n_streams)
