@@ -52,9 +52,33 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_hash():
+    """12 hex digits over every kernel / host source of the library: lr_version() carries it, so that a counter file
+    (profiles/pmc_c3.json) or a bench line can be tied to the exact kernels it was measured on (the GPU box has no .git)."""
+    import hashlib
+    h = hashlib.sha1()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")))
+    for path in [os.path.join(CSRC, f) for f in names] + [os.path.join(INCLUDE, "lucid_raster.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
+def _write_hash_header():
+    path = os.path.join(OBJDIR, "lr_src_hash.h")
+    text = f'#define LR_SRC_HASH "{source_hash()}"\n'
+    old = open(path).read() if os.path.exists(path) else None
+    if old != text:                       # untouched when the sources are: api.o is only rebuilt when the hash moves
+        with open(path, "w") as f:
+            f.write(text)
+    return path
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
+    hash_header = _write_hash_header()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "lucid_raster.h"), os.path.abspath(__file__)]
     objs = []
     procs = []
@@ -62,8 +86,9 @@ def build(force=False, verbose=False):
         sp = os.path.join(CSRC, src)
         op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(op)
-        if force or _stale(op, [sp] + headers):
-            cmd = [cc, "-c", sp, "-o", op] + COMMON_FLAGS + extra + os.environ.get("LR_EXTRA_HIPCC_FLAGS", "").split()
+        deps = [sp] + headers + ([hash_header] if src == "api.hip" else [])
+        if force or _stale(op, deps):
+            cmd = [cc, "-c", sp, "-o", op] + COMMON_FLAGS + ["-I", OBJDIR] + extra + os.environ.get("LR_EXTRA_HIPCC_FLAGS", "").split()
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -38,10 +38,18 @@ def test_two_ranks_equal_one_rank_on_the_flat_gradient_bucket(hip_device, tmp_pa
     assert np.abs(a - want).max() <= 2e-5 * np.abs(want).max()       # same sum, different association across ranks / chunks
 
 
-def test_bench_runs_under_two_ranks_and_reports_the_world_size(hip_device):
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_runs_under_two_ranks_and_reports_the_world_size(hip_device, scaling):
+    """N > 1 defaults to the stated configuration (BASELINE.json config 3): the step's views are SHARED by the ranks, one
+    all-reduce per step ("strong"); --scaling weak keeps that many views per rank."""
+    extra = [] if scaling == "strong" else ["--scaling", "weak"]
     r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gaussians", "100000",
-                      "--views", "4", "--resolution", "640x360", "--no-cpu-baseline"], 29613)
+                      "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0"] + extra,
+                  29613 if scaling == "strong" else 29615)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["dist_world_size"] == 2 and line["config"]["dist_backend"] == "gloo"
-    assert line["scaling"] == "weak" and line["value"] > 0 and line["entry_points"] is None
+    assert line["scaling"] == scaling and line["value"] > 0 and line["entry_points"] is None
+    cfg = line["config"]
+    assert cfg["views_per_step"] == (4 if scaling == "strong" else 8) and cfg["views_per_rank_per_step"] == (2 if scaling == "strong" else 4)
+    assert cfg["allreduce_bytes_per_step"] == cfg["grad_bucket_bytes"]          # few views per rank: one all-reduce per step
