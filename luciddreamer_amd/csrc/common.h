@@ -238,7 +238,7 @@ void launch_preprocess(const ViewParams& vp, const float* means3D, const float* 
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
                        uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
-                       GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, hipStream_t s);
+                       GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, bool sparse_view_hint, hipStream_t s);
 // zeroes the per-call part of the header and the chunk sums that k_preprocess adds into (chunk_sums == nullptr there: none)
 void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s);
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
