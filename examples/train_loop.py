@@ -84,8 +84,8 @@ def train(args, log=print):
     model, cams, targets = build(args, dev)
     bg = torch.zeros(3, device=dev)
     # no host round trip per forward ("Host sync"); instance counts drift while the cloud is
-    # optimised, so the capacity is taken over a few views, with generous headroom, and an overflow only warns
-    config.set_async(not args.exact, headroom=2.0, warm_calls=2 * len(cams), on_overflow="warn")
+    # optimised, so the capacity is taken over the views of the path, with generous headroom
+    config.set_async(not args.exact, headroom=1.5, warm_calls=len(cams))     # overflowed views are re-rendered (default policy)
     losses = []
     gen = torch.Generator().manual_seed(0)
     torch.cuda.synchronize()
@@ -108,7 +108,7 @@ def train(args, log=print):
             log(f"iter {it:5d}  loss {losses[-1][1]:.5f}  gaussians {losses[-1][2]}")
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    config.set_async(False)
+    config.set_async(True)              # back to the library defaults
     log(f"{args.iters} iterations in {dt:.2f} s = {dt / args.iters * 1e3:.3f} ms/iteration")
     return losses, dt
 

@@ -80,8 +80,11 @@ size_t lr_binning_bytes(long long R);
  * binning_capacity  > 0  (async mode): no host synchronisation at all.  The binning buffer is
  *     sized for `binning_capacity` tile instances; num_rendered stays in the geom buffer header.
  *     If the view needs more, nothing is written out of bounds, the overflow flag in the header
- *     is set and lr_check (or lr_views_check for the multi-view entry points) returns LR_ERR_OVERFLOW; lr_backward
- *     does not look at the flag (it would cost a host synchronisation) and differentiates the truncated image.
+ *     is set and lr_check (or lr_views_check for the multi-view entry points) returns LR_ERR_OVERFLOW.  The HOST side
+ *     of lr_backward does not look at the flag (it would cost a synchronisation), its KERNELS do: the backward of an
+ *     overflowed view writes nothing -- its gradients are zero (write mode) or it adds nothing (accumulate mode); a
+ *     truncated instance list is never differentiated.  Callers that need that view's gradients call lr_check after
+ *     the step and run the view again with binning_capacity = 0 (the Python operator does this by itself).
  *
  * out_color [3,H,W], out_depth [1,H,W], radii [P] are fully written (no pre-fill needed).
  */

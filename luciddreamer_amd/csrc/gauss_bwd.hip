@@ -359,6 +359,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
     const int lane = threadIdx.x;
     const uint32_t n = hdr->num_compact;
     if (n == 0) return;
+    if (hdr->overflow != 0u) return;         // async mode: an overflowed view contributes nothing (see k_render_bwd)
     // per-instance partial sums written by k_render_bwd (48-byte slots, contiguous per Gaussian in emission
     // order); slots at or beyond num_sorted were never built (async-mode overflow) and are ignored
     const float4* __restrict__ inst_grad =

@@ -200,6 +200,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 
     const int tile = blend_tile(tile_map, num_tiles);
     if (tile < 0) return;
+    // async mode: a view that needed more tile instances than its binning buffer held (flag set by the forward's scan) is
+    // NOT differentiated -- its instance list is truncated.  k_gauss_bwd skips it as well: the view contributes zero.
+    if (hdr->overflow != 0u) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // this wave's box: 16x8 (pixel A left, pixel B right quadrant), or with QUAD the 8x8 quadrant (w&1, w>>1), pixel A only

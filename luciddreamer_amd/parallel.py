@@ -209,11 +209,22 @@ class ViewStreams:
         self._caller = None
 
     def begin_step(self):
+        from . import config
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(cur)
         self._prev_bwd = None
         self._caller = cur
+        # several views in flight: a backward must not wait for its forward's header copy (config "rerender" does); an
+        # overflowed view contributes zero gradients and is reported by the deferred check instead
+        config._override.append("drop")
+        self._policy_pushed = True
+
+    def _pop_policy(self):
+        from . import config
+        if getattr(self, "_policy_pushed", False):
+            config._override.pop()
+            self._policy_pushed = False
 
     def run_view(self, forward_fn: Callable, backward_fn: Callable):
         s = self.streams[self._i % len(self.streams)]
@@ -231,6 +242,7 @@ class ViewStreams:
         except BaseException:
             if self._caller is not None:
                 torch.cuda.set_stream(self._caller)
+            self._pop_policy()
             raise
         self._i += 1
 
@@ -240,6 +252,7 @@ class ViewStreams:
         for s in self.streams:
             cur.wait_stream(s)
         self._caller = None
+        self._pop_policy()
 
 
 class ViewBatch:

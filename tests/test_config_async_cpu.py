@@ -1,5 +1,6 @@
-"""CPU: the host logic of async mode (luciddreamer_amd.config) -- high-water mark, warm calls, the deferred overflow
-check over header tickets and its two policies -- with the binding's two ticket functions replaced by a fake that
+"""CPU: the host logic of async mode (luciddreamer_amd.config) -- high-water mark, warm calls, the overflow policies
+("rerender": the backward claims its forward's header; "drop" / "raise": deferred check over header tickets) -- with the
+binding's two ticket functions replaced by a fake that
 completes read-backs on demand.  The real lr_header_post / lr_header_poll are exercised on the GPU
 (tests/test_gpu_parity.py::test_header_tickets)."""
 import types
@@ -41,9 +42,11 @@ def fake(monkeypatch):
     monkeypatch.setattr(luciddreamer_amd, "_C", f, raising=False)
     config.set_async(False)
     config.reset()
+    config.dropped_views = config.rerendered_views = 0
     yield f
     config._pending.clear()
-    config.set_async(False)
+    config._override.clear()
+    config.set_async(True)                     # the module default
     config._hwm.clear()
     config._seen.clear()
 
@@ -57,26 +60,72 @@ def _header(num_rendered, overflow=0, trap=0, instances=None):
     return [num_rendered, overflow, trap, 0, 0, inst, inst, 0]
 
 
+def test_defaults_are_async_with_rerender_and_two_warm_calls():
+    import importlib
+    import os
+    assert os.environ.get("LUCID_RASTER_EXACT", "0") != "1"
+    mod = importlib.reload(config)
+    assert mod.is_async() and mod.current_policy() == "rerender" and mod._warm_calls == 2
+
+
 def test_exact_until_a_mark_exists_then_capacity_from_the_mark(fake):
     means = torch.zeros(1000, 3)
     rs = _rs()
     assert config.capacity_for(means, rs) == 0                      # async off: always exact
-    config.set_async(True, headroom=1.5)
+    config.set_async(True, headroom=1.5, warm_calls=1)
     assert config.capacity_for(means, rs) == 0                      # first sighting: measured exactly
     config.note_forward(means, rs, 10_000, None, 0)                 # an exact forward feeds the mark directly, no ticket
     assert fake.next == 0
     cap = config.capacity_for(means, rs)
     assert cap == int(10_000 * 1.5) + 4096
+    assert config.capacity_for(means, rs, differentiable=False) == 0      # no backward will follow: exact (render-only loops)
     assert config.capacity_for(torch.zeros(0, 3), rs) == 0          # empty cloud: nothing to size
     assert config.capacity_for(torch.zeros(1000, 3), _rs(32, 32)) == 0      # another (P, H, W): its own first sighting
 
 
+def test_rerender_policy_the_backward_claims_its_header(fake):
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, headroom=1.0, warm_calls=1, wait=True)    # on_overflow="rerender" is the default; strict form
+    config.note_forward(means, rs, 1_000, None, 0)
+    cap = config.capacity_for(means, rs)
+    t_ok, own_ok = config.note_forward(means, rs, -1, _header(900), cap)
+    t_over, own_over = config.note_forward(means, rs, -1, _header(50_000, overflow=1), cap)
+    assert fake.next == 2 and len(config._pending) == 2
+    config.capacity_for(means, rs)                                   # a poll in between leaves owned tickets alone
+    assert len(config._pending) == 2 and not fake.polled
+    assert config.claim(t_over) is True                              # blocks on ITS ticket only; overflowed -> re-render
+    assert fake.polled == [(t_over, True)]
+    assert config.rerendered_views == 1 and config.dropped_views == 0
+    assert config.capacity_for(means, rs) == 50_000 + 4096            # the mark follows the true count
+    assert config.claim(t_ok) is False
+    assert not config._pending
+    assert config.claim(t_ok) is False                               # claimed twice: nothing to do
+    # default form (wait=False): a header that has not arrived is not waited for -- the ticket goes to the deferred check
+    config.set_async(True, headroom=1.0, warm_calls=1)
+    t4, own4 = config.note_forward(means, rs, -1, _header(60_000, overflow=1), cap)
+    assert config.claim(t4) is False and fake.polled[-1] == (t4, False) and len(config._pending) == 1
+    fake.complete(t4)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        config.drain()
+    assert any("ZERO" in str(x.message) for x in w) and config.dropped_views == 1
+    t5, own5 = config.note_forward(means, rs, -1, _header(70_000, overflow=1), cap)
+    fake.complete(t5)                                                # ... and one that has arrived is acted upon
+    assert config.claim(t5) is True and config.rerendered_views == 2
+    # a forward whose graph is released without a backward: the ticket falls to the deferred poll
+    t3, own3 = config.note_forward(means, rs, -1, _header(700), cap)
+    del own3
+    fake.complete(t3)
+    config.drain()
+    assert not config._pending
+
+
 def test_deferred_check_polls_in_order_and_raises_the_mark(fake):
     means, rs = torch.zeros(500, 3), _rs()
-    config.set_async(True, headroom=1.2)
+    config.set_async(True, headroom=1.2, warm_calls=1, on_overflow="drop")
     config.note_forward(means, rs, 5_000, None, 0)
     cap = config.capacity_for(means, rs)
-    config.note_forward(means, rs, -1, _header(7_000, instances=6_500), cap)    # async forward: a ticket, nothing blocks
+    assert config.note_forward(means, rs, -1, _header(7_000, instances=6_500), cap) is None    # a ticket, nothing blocks
     config.note_forward(means, rs, -1, _header(6_000, instances=5_500), cap)
     assert fake.next == 2 and len(config._pending) == 2
     config.capacity_for(means, rs)                                   # polls: nothing has completed
@@ -89,32 +138,42 @@ def test_deferred_check_polls_in_order_and_raises_the_mark(fake):
     assert not config._pending
 
 
-def test_overflow_policies(fake):
+def test_deferred_overflow_policies(fake):
     means, rs = torch.zeros(500, 3), _rs()
-    config.set_async(True, headroom=1.0)
+    config.set_async(True, headroom=1.0, warm_calls=1, on_overflow="raise")
     config.note_forward(means, rs, 1_000, None, 0)
     cap = config.capacity_for(means, rs)
     config.note_forward(means, rs, -1, _header(50_000, overflow=1), cap)
-    with pytest.raises(RuntimeError, match="capacity"):
-        config.drain()                                               # blocks on the ticket, then raises (default policy)
+    with pytest.raises(RuntimeError, match="ZERO"):
+        config.drain()                                               # blocks on the ticket, then raises
     assert fake.polled[-1] == (0, True)
     assert config.capacity_for(means, rs) == 50_000 + 4096            # raised from the true count either way
-    config.set_async(True, headroom=1.0, on_overflow="warn")
+    config.set_async(True, headroom=1.0, warm_calls=1, on_overflow="drop")
     config.note_forward(means, rs, -1, _header(80_000, overflow=1), cap)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         config.drain()
-    assert any("binning capacity" in str(x.message) for x in w)
+    assert any("binning capacity" in str(x.message) and "ZERO" in str(x.message) for x in w)
+    assert config.dropped_views == 2
     config.note_forward(means, rs, -1, _header(10, trap=1), cap)
     with pytest.raises(RuntimeError, match="prefiltered"):
         config.drain()
     with pytest.raises(ValueError):
-        config.set_async(True, on_overflow="ignore")
+        config.set_async(True, on_overflow="warn")                   # the round-2 policy (train on truncated gradients) is gone
+    # a temporary policy (what parallel.ViewStreams does around its views)
+    config.set_async(True, warm_calls=1)
+    assert config.current_policy() == "rerender"
+    with config.overflow_policy("drop"):
+        assert config.current_policy() == "drop"
+        assert config.note_forward(means, rs, -1, _header(10), cap) is None
+    assert config.current_policy() == "rerender"
+    fake.complete(*range(fake.next))
+    config.drain()
 
 
 def test_check_every_samples_and_warm_calls_stay_exact(fake):
     means, rs = torch.zeros(500, 3), _rs()
-    config.set_async(True, check_every=3, warm_calls=2)
+    config.set_async(True, check_every=3, warm_calls=2, on_overflow="drop")
     assert config.capacity_for(means, rs) == 0
     config.note_forward(means, rs, 1_000, None, 0)
     assert config.capacity_for(means, rs) == 0                       # second warm call: still exact
