@@ -84,12 +84,12 @@ constexpr int PART_BLOCKS_MAX = 256;        // workgroups of the count / scatter
 constexpr int PART_THREADS = 1024;
 constexpr int PART_MIN_GAUSS = 1024;        // emitting Gaussians per workgroup before another workgroup is used
 constexpr int TSORT_LDS = 256;              // bin entries sorted by one wave (2 KB of LDS)
-constexpr int TSORT_NET_LDS = 768;          // bin entries of the 256-thread bitonic class (6 KB of LDS)
-constexpr int TSORT_THREADS = 512;          // threads of the bucket-sort class
+constexpr int TSORT_GROUP_LDS = 1024;        // bin entries the four waves of a k_tile_sort_small workgroup sort together (8 KB)
+constexpr int TSORT_THREADS = 512;          // threads of k_tile_sort_large (bins of more than 1024 entries)
 constexpr int TSORT_MID_LDS = 4096;         // ... its bin entries (32 KB of words + 16 KB of bucket counters)
-constexpr int TSORT_BIG_LDS = 16384;        // ... the large-bin kernel (128 KB); beyond: in place in global memory
+constexpr int TSORT_BIG_LDS = 16384;        // ... entries sorted in LDS when the launch asks for 128 KB; beyond: in place in global memory
 constexpr int TSORT_BIG_BLOCKS = 256;
-constexpr int TSORT_CLASS_BLOCKS = 2048;     // grid cap of the 257..768 and 769..4096 classes (grid-stride over the bins)
+constexpr int TSORT_CLASS_BLOCKS = 2048;     // grid cap of k_tile_sort_large (queue-fed)
 struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)
 PartPlan part_plan(int num_tiles);
 
@@ -265,7 +265,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                         const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
-                        TileBinTimes* t, hipStream_t s);
+                        long long bin_bound_hint, TileBinTimes* t, hipStream_t s);
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).

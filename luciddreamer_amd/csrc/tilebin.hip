@@ -23,14 +23,14 @@
 //                                        the same walk again; every hit takes the next free position of its bin from
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
-//   k_tile_sort / _net / _mid / _big     one workgroup per bin sorts its words in LDS (bitonic network; three size
-//                                        classes: <= 256 entries by one wave, <= 768 (network), <= 4096 (bucket sort), <= 16384 with 128 KB of LDS;
-//                                        beyond that in place in global memory).
+//   k_tile_sort_small / _large           every bin's words are sorted in LDS: <= 256 entries by one wave, <= 1024 by a
+//                                        workgroup (bitonic network), <= 4096 bucket sort, beyond that the network again
+//                                        (in LDS up to 16384 entries when the launch has the room, else in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
 //                                        repeatable, whatever order the scatter produced.
 //
-// 9 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
+// 7 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
 // atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
 #include <mutex>
 #include "common.h"
@@ -226,7 +226,7 @@ __device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, i
 // Exclusive prefix over the bins, evaluated by every scatter workgroup for itself, into its LDS cursor array
 // (cursor = bin start + this workgroup's base inside the bin); workgroup 0 also publishes bin_start and the per-tile
 // ranges (a bin is a tile when sub_shift == 0; otherwise the ranges are zeroed here and filled by the per-bin sort) and
-// builds the queue of bins that only k_tile_sort_big can take (more than 4096 entries).
+// builds the queue of the bins k_tile_sort_large takes (more than 1024 entries).
 // Global memory is touched with consecutive lanes on consecutive words only (the totals are staged through the cursor
 // array; a thread then scans 16 CONSECUTIVE bins out of LDS, conflict-free thanks to bin_slot's padding): with each thread
 // loading its own 64-byte run straight from global memory this prologue cost 12 us of the kernel's 32.
@@ -259,10 +259,10 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
     if (threadIdx.x == PART_THREADS - 1) s_total = run + sum;
     uint32_t q = 0, nbig = 0;
     if (publish) {
-        // the queue of bins for k_tile_sort_big, in bin order, by a second block scan (no atomics: returning global
+        // the queue of bins for k_tile_sort_large, in bin order, by a second block scan (no atomics: returning global
         // atomics on one word cost ~45 ns each on this part, and a dense 512^2 view queues every tile)
 #pragma unroll
-        for (int i = 0; i < PER; i++) nbig += v[i] > (uint32_t)TSORT_MID_LDS ? 1u : 0u;
+        for (int i = 0; i < PER; i++) nbig += v[i] > (uint32_t)TSORT_GROUP_LDS ? 1u : 0u;
         uint32_t binc = nbig;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -280,7 +280,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
         const int bin = base + i;
         if (bin < bins) {
             s_bin[bin_slot(bin)] = run;                   // exclusive start of the bin
-            if (publish && v[i] > (uint32_t)TSORT_MID_LDS) big_queue[1 + q++] = (uint32_t)bin;
+            if (publish && v[i] > (uint32_t)TSORT_GROUP_LDS) big_queue[1 + q++] = (uint32_t)bin;
         }
         run += v[i];
     }
@@ -444,40 +444,46 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
     }
 }
 
-// Four size classes.  k_tile_sort: one WAVE per bin, up to 256 entries in 2 KB of LDS (every workgroup of the grid is
-// resident at once; a C3 tile holds ~50 entries).  k_tile_sort_net: 256 threads, up to 768 entries, bitonic network.
-// k_tile_sort_mid: 512 threads, up to 4096 entries, bucket sort.
-// k_tile_sort_big: fed by the queue the scatter kernel built, 1024 threads, up to 16384 entries in 128 KB of LDS, beyond
-// that in place in global memory.  All three are always launched; workgroups whose bin belongs to another class return.
-__global__ void __launch_bounds__(64)
-k_tile_sort(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
-            const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
-            uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
-{
-    __shared__ unsigned long long s_a[TSORT_LDS];
-    const int bin = (int)blockIdx.x;
-    const uint32_t n = bin_total[bin];
-    if (n == 0) return;
-    if (n > (uint32_t)TSORT_LDS) return;               // k_tile_sort_mid's, or queued for k_tile_sort_big by the scatter kernel
-    const uint32_t start = bin_start[bin];
-    for (uint32_t i = threadIdx.x; i < n; i += 64) s_a[i] = words[start + i];
-    __syncthreads();
-    if (n > 1) bitonic_sort(s_a, n, threadIdx.x, 64u, [] { __syncthreads(); });
-    write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 64u, point_list, ranges);
-}
-
-// 257..768 entries (the tiles of the dense 1080p / 1440p clouds): the bitonic network on 256 threads in 6 KB of LDS.  At
-// these sizes its ~45 cheap stages beat the bucket sort's scan and two atomic passes (dense 1 M cloud at 1080p: 0.087 vs
-// 0.152 ms per view), and the small footprint keeps many bins resident per CU.
+// Two launches for all bin sizes (round 2 had four, three of which found nothing to do on a sparse view and still cost a
+// launch each):
+//   k_tile_sort_small  256 threads = 4 waves per workgroup.  Part A of the grid: one workgroup per 4 consecutive bins, a bin
+//                      of up to 256 entries (a C3 tile holds ~70) sorted by ONE wave in its own 2 KB of LDS, no block
+//                      barrier involved.  Part B (up to 2048 more workgroups, striding over the bins): bins of 257..1024
+//                      entries by a whole workgroup with the four slices as one 8 KB array (the dense 1080p / 1440p
+//                      clouds: 400..700 per tile).
+//   k_tile_sort_large  fed by the queue the scatter kernel built (bins of more than 1024 entries), 512 threads: up to
+//                      4096 entries the bucket sort, beyond that the bitonic network -- in LDS when the launch was given
+//                      room for it (lds_entries), else in place in global memory.
 __global__ void __launch_bounds__(256)
-k_tile_sort_net(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
-                const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
-                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+                  const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
+                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
-    __shared__ unsigned long long s_a[TSORT_NET_LDS];
-    for (int bin = (int)blockIdx.x; bin < bins; bin += (int)gridDim.x) {          // grid: see launch_tile_binning
+    __shared__ unsigned long long s_a[4 * TSORT_LDS];         // 4 x 256 entries = TSORT_GROUP_LDS
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    if ((int)blockIdx.x < groups4) {
+        // part A: workgroup g takes bins 4 g .. 4 g + 3, one per wave, if they hold at most 256 entries
+        const int bin = (int)blockIdx.x * 4 + w;
+        const uint32_t n = bin < bins ? bin_total[bin] : 0u;
+        if (n == 0 || n > (uint32_t)TSORT_LDS) return;
+        unsigned long long* a = s_a + w * TSORT_LDS;
+        const uint32_t start = bin_start[bin];
+        for (uint32_t i = l; i < n; i += 64) a[i] = words[start + i];
+        // one wave, its own slice: LDS operations of a wave execute in order, so a wave-level fence is all the exchange
+        // between its lanes needs (no workgroup barrier anywhere in this part)
+        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+        wsync();
+        if (n > 1) bitonic_sort(a, n, (uint32_t)l, 64u, wsync);
+        write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges);
+        return;
+    }
+    // part B: the remaining workgroups walk the bins with a stride and take those of 257..1024 entries, one at a time, with
+    // the four slices as one array (a sparse view has none: these workgroups read their bins' counts and leave)
+    const int first = (int)blockIdx.x - groups4, stride = (int)gridDim.x - groups4;
+    for (int bin = first; bin < bins; bin += stride) {
         const uint32_t n = bin_total[bin];
-        if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_NET_LDS) continue;
+        if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_GROUP_LDS) continue;
         const uint32_t start = bin_start[bin];
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
@@ -487,7 +493,7 @@ k_tile_sort_net(int bins, int sub_shift, int slot_bits, int num_tiles, const uin
     }
 }
 
-// 769..4096 entries: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
+// 1025..4096 entries: a bucket sort.  The sort key of a word is everything above its slot bits (sub-tile, depth bits); keys
 // are mapped monotonically onto ~n buckets between the bin's smallest and largest key, counted, scanned and scattered
 // with LDS atomics (order inside a bucket arbitrary), then every bucket -- one or two entries on average -- is put in
 // order by an insertion sort on the full 64-bit word.  Any monotone map keeps the result exact; the map only decides how
@@ -495,22 +501,38 @@ k_tile_sort_net(int bins, int sub_shift, int slot_bits, int num_tiles, const uin
 // falls back to the bitonic network.  ~8 barriers instead of the network's 66 at these sizes (dense 512^2 view: 0.145 ->
 // 0.052 ms).
 __global__ void __launch_bounds__(TSORT_THREADS)
-k_tile_sort_mid(int bins, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
-                const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
-                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entries, const uint32_t* __restrict__ bin_start,
+                  const uint32_t* __restrict__ bin_total, unsigned long long* __restrict__ words,
+                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue)
 {
     constexpr int PER = TSORT_MID_LDS / TSORT_THREADS;                // 8 items / buckets per thread
-    __shared__ unsigned long long s_out[TSORT_MID_LDS];
+    extern __shared__ unsigned long long s_out[];                     // [max(TSORT_MID_LDS, lds_entries)]
     __shared__ uint32_t s_cnt[TSORT_MID_LDS];
     __shared__ unsigned long long s_red[2 * (TSORT_THREADS / 64)];
     __shared__ uint32_t s_wave[TSORT_THREADS / 64];
     __shared__ uint32_t s_bad;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int bin = (int)blockIdx.x; bin < bins; bin += (int)gridDim.x) {          // grid: see launch_tile_binning
+    const uint32_t count = big_queue[0];
+    for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x) {
+    const int bin = (int)big_queue[1 + qi];
     const uint32_t n = bin_total[bin];
-    if (n <= (uint32_t)TSORT_NET_LDS || n > (uint32_t)TSORT_MID_LDS) continue;
     const uint32_t start = bin_start[bin];
     __syncthreads();
+    if (n > (uint32_t)TSORT_MID_LDS) {
+        if (n <= lds_entries) {
+            for (uint32_t i = tid; i < n; i += TSORT_THREADS) s_out[i] = words[start + i];
+            __syncthreads();
+            bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+            write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+        } else {
+            // larger than the LDS of this launch: the same network in place in global memory (one workgroup, L2-resident;
+            // slow, but a single tile with that many splats is slow to blend anyway)
+            unsigned long long* a = words + start;
+            bitonic_sort(a, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __threadfence(); __syncthreads(); });
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+        }
+        continue;
+    }
     unsigned long long item[PER];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
@@ -591,33 +613,6 @@ k_tile_sort_mid(int bins, int sub_shift, int slot_bits, int num_tiles, const uin
     }
 }
 
-__global__ void __launch_bounds__(1024)
-k_tile_sort_big(int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
-                const uint32_t* __restrict__ bin_total, unsigned long long* __restrict__ words,
-                uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue)
-{
-    extern __shared__ unsigned long long s_big[];        // [TSORT_BIG_LDS]
-    const uint32_t count = big_queue[0];
-    for (uint32_t q = blockIdx.x; q < count; q += gridDim.x) {
-        const int bin = (int)big_queue[1 + q];
-        const uint32_t n = bin_total[bin], start = bin_start[bin];
-        if (n <= (uint32_t)TSORT_BIG_LDS) {
-            for (uint32_t i = threadIdx.x; i < n; i += 1024) s_big[i] = words[start + i];
-            __syncthreads();
-            bitonic_sort(s_big, n, threadIdx.x, 1024u, [] { __syncthreads(); });
-            write_sorted(s_big, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024u, point_list, ranges);
-        } else {
-            // larger than the LDS: the same network in place in global memory (one workgroup, L2-resident; slow, but a
-            // single tile with more than 16384 splats is slow to blend anyway)
-            unsigned long long* a = words + start;
-            __syncthreads();
-            bitonic_sort(a, n, threadIdx.x, 1024u, [] { __threadfence(); __syncthreads(); });
-            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 1024u, point_list, ranges);
-        }
-        __syncthreads();
-    }
-}
-
 }  // namespace
 
 PartPlan part_plan(int num_tiles)
@@ -641,9 +636,9 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                         const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
-                        TileBinTimes* t, hipStream_t s)
+                        long long bin_bound_hint, TileBinTimes* t, hipStream_t s)
 {
-    // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort 128 KB.  The attribute is
+    // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort up to 128 KB.  The attribute is
     // set once per DEVICE (a process may drive several; runtimes that keep it per device would otherwise refuse the
     // > 64 KB launches on the second one)
     {
@@ -657,7 +652,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                                     (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_part<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (PART_BINS_MAX + PART_BINS_MAX / 16 + 1) * 4) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_big), hipFuncAttributeMaxDynamicSharedMemorySize,
+                hipFuncSetAttribute(reinterpret_cast<const void*>(k_tile_sort_large), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     TSORT_BIG_LDS * 8) != hipSuccess)
                 return -1;
             if (device >= 0 && device < 64) attr_done[device] = true;
@@ -683,19 +678,18 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                        vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words);
     if (t) t->mark(3, s);
-    hipLaunchKernelGGL(k_tile_sort, dim3(pp.bins), dim3(64), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
-                       bin_start, bin_total, words, point_list, ranges);
-    // the two middle classes walk the bins with a capped grid: a launch that finds nothing in its size class -- every view of
-    // a sparse scene -- then costs 2048 workgroups instead of one per bin (beside a blend kernel that fills the CUs, 8160
-    // workgroups of 48 KB of LDS each took 34 us to be handed out and retire); +1.1 % on the three-stream C3 headline, +0.7
-    // to 1.6 % on the dense shapes, where 2048 is still more than fit on the chip at once
-    const int class_blocks = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;
-    hipLaunchKernelGGL(k_tile_sort_net, dim3(class_blocks), dim3(256), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
-                       bin_start, bin_total, words, point_list, ranges);
-    hipLaunchKernelGGL(k_tile_sort_mid, dim3(class_blocks), dim3(TSORT_THREADS), 0, s, pp.bins, pp.sub_shift, slot_bits, num_tiles,
-                       bin_start, bin_total, words, point_list, ranges);
-    hipLaunchKernelGGL(k_tile_sort_big, dim3(TSORT_BIG_BLOCKS), dim3(1024), (size_t)TSORT_BIG_LDS * 8, s, pp.sub_shift, slot_bits,
-                       num_tiles, bin_start, bin_total, words, point_list, ranges, big_queue);
+    const int groups4 = (pp.bins + 3) / 4;
+    const int part_b = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;
+    hipLaunchKernelGGL(k_tile_sort_small, dim3(groups4 + part_b), dim3(256), 0, s, pp.bins, groups4, pp.sub_shift, slot_bits,
+                       num_tiles, bin_start, bin_total, words, point_list, ranges);
+    // the large bins: LDS for the bucket sort (32 KB of words; three workgroups per CU) unless the AVERAGE bin is already
+    // beyond it -- then 128 KB, so that bins of up to 16384 entries are sorted in LDS (a hint for speed only: a bin that
+    // does not fit this launch's LDS is sorted in place in global memory).  Capped grid: a sparse view queues nothing
+    const bool huge = bin_bound_hint / (long long)pp.bins > (long long)TSORT_MID_LDS;
+    const uint32_t lds_entries = huge ? (uint32_t)TSORT_BIG_LDS : (uint32_t)TSORT_MID_LDS;
+    const int large_blocks = pp.bins < (huge ? TSORT_BIG_BLOCKS : TSORT_CLASS_BLOCKS) ? pp.bins : (huge ? TSORT_BIG_BLOCKS : TSORT_CLASS_BLOCKS);
+    hipLaunchKernelGGL(k_tile_sort_large, dim3(large_blocks), dim3(TSORT_THREADS), (size_t)lds_entries * 8, s, pp.sub_shift,
+                       slot_bits, num_tiles, lds_entries, bin_start, bin_total, words, point_list, ranges, big_queue);
     if (t) t->mark(4, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;        // a refused launch (LDS attribute, grid) surfaces here, not at the blend
 }
