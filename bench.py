@@ -95,6 +95,7 @@ class Workload:
         if resolution:
             W, H = resolution
         self.name, self.P, self.W, self.H, self.V, self.dev, self.world = name, P, W, H, V, dev, world
+        self.args = args
         self.degree = args.sh_degree
         cloud = synthetic.make_cloud(P, kind, 0)
         # views of one step over all ranks: V per rank (weak) or V in total, view i -> rank i mod world (strong)
@@ -168,6 +169,23 @@ class Workload:
             # views to hide a collective behind: it doubles the bytes on the links, which a step of a few views per
             # rank -- communication bound -- cannot afford
             self.chunks = chunks = (2 if len(self.cams) >= 8 else 1) if self.world > 1 else 1
+            if api == "views" and getattr(self.args, "exchange", "allreduce") == "sharded-adam":
+                # the step as a TRAINING step (not the metric: it adds the optimizer): no all-reduce -- reduce-scatter of the
+                # bucket, Adam on this rank's shard, all-gather of the parameters (parallel.ShardedAdam)
+                ordered = [torch.nn.Parameter(named[k].detach()) for k in parallel.ChunkedViewStep.ORDER]
+                named = dict(zip(parallel.ChunkedViewStep.ORDER, ordered))
+                bucket = parallel.ShardedAdam.make_buckets(ordered)
+                self.batch = parallel.ChunkedViewStep(self.cams, [self.grad_color] * len(self.cams), named, self.degree,
+                                                      self.bg, self.capacity, n_streams=streams, chunks=1, grads=bucket)
+                self.opt = parallel.ShardedAdam(ordered, bucket, [1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3])
+                self.grads = self.batch.grads
+                batch, opt = self.batch, self.opt
+
+                def step():
+                    self.m2d_grad.zero_()
+                    batch.run(self.m2d_grad, reduce=False)
+                    opt.step()
+                return step
             if api == "views":
                 self.batch = parallel.ChunkedViewStep(self.cams, [self.grad_color] * len(self.cams), named, self.degree,
                                                       self.bg, self.capacity, n_streams=streams, chunks=chunks)
@@ -331,6 +349,9 @@ def main():
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
                     help="N > 1: strong = the workload's views per STEP shared by the ranks (BASELINE.json config 3; auto picks it), "
                          "weak = that many views per rank")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded-adam"],
+                    help="views API: allreduce = the metric's step (gradients all-reduced); sharded-adam = a training step, "
+                         "reduce-scatter + Adam on the rank's shard + all-gather of the parameters (extra work: not the metric)")
     ap.add_argument("--sustain-seconds", type=float, default=1.0,
                     help="after the K contract steps, time the same step for at least this long (reported as `sustained`)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
@@ -412,7 +433,7 @@ def main():
                                     + ")") if world > 1 else "dp1",
                     "allreduce_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
                     "dist_backend": backend, "dist_world_size": backend_world, "streams_per_rank": args.streams,
-                    "api": args.api, "host_issue_ms_per_step": round(host_issue_ms, 3),
+                    "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
         line = {
             "metric": metric,

@@ -74,10 +74,13 @@ class FlatGrads:
 
     ALIGN = 4      # floats: every segment starts on a 16-byte boundary (the HIP kernels accumulate with 16-byte accesses)
 
-    def __init__(self, params: Sequence[torch.Tensor]):
+    def __init__(self, params: Sequence[torch.Tensor], multiple_of: int = 1):
+        """multiple_of: round the bucket length up to a multiple of this many floats (ShardedAdam: world x 4, so that
+        every rank's shard of a reduce-scatter starts on a 16-byte boundary)."""
         self.params = list(params)
         pad = lambda n: (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         total = sum(pad(p.numel()) for p in self.params)
+        total = (total + multiple_of - 1) // multiple_of * multiple_of
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         off = 0
@@ -113,6 +116,107 @@ class FlatGrads:
         return work
 
 
+class FlatParams:
+    """The parameters themselves as views of ONE contiguous fp32 buffer, laid out like a FlatGrads bucket of the same
+    tensors (same 16-byte-padded segments): `p.data` of every parameter is re-pointed into the buffer (values copied
+    once), so the all-gather of ShardedAdam updates every parameter in place with no packing."""
+
+    def __init__(self, params: Sequence[torch.Tensor], like: FlatGrads):
+        self.params = list(params)
+        self.flat = torch.zeros_like(like.flat)
+        self.views = []
+        for p, (off, n) in zip(self.params, like.segments):
+            v = self.flat[off:off + n].view_as(p)
+            v.copy_(p.detach())
+            p.data = v
+            self.views.append(v)
+
+
+def _adam_pieces_hip(pieces, beta1, beta2, eps, step):
+    """Default arithmetic of ShardedAdam: lr_adam_step (adam.hip) over up to 16 slices per launch."""
+    import ctypes
+    from . import _lib
+    L = _lib.lib()
+    for i in range(0, len(pieces), 16):
+        chunk = pieces[i:i + 16]
+        n = len(chunk)
+        arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in chunk])
+        numel = (ctypes.c_ulonglong * n)(*[it[0].numel() for it in chunk])
+        lrs = (ctypes.c_double * n)(*[float(it[4]) for it in chunk])
+        dev = chunk[0][0].device
+        with torch.cuda.device(dev):
+            rc = L.lr_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lrs, float(beta1), float(beta2), float(eps),
+                                int(step), torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.raise_for(rc, "lr_adam_step")
+
+
+class ShardedAdam:
+    """Optimizer step of the data-parallel loop with the exchange split in two and the optimizer sharded (ZeRO-1 shape):
+
+        reduce_scatter(SUM) of the flat gradient bucket   rank r ends up with floats [r L/n, (r+1) L/n) of the sum
+        Adam on that shard                                 moments exist for the shard only
+        all_gather of the flat PARAMETER buffer            every rank has every updated parameter again
+
+    The links carry what one all-reduce carries (a ring / mesh all-reduce IS a reduce-scatter followed by an all-gather,
+    2 (n-1)/n x 236 B per Gaussian per rank), but the 28 B per element of optimizer traffic and the two moment buffers
+    (2 x 236 B per Gaussian) are divided by the number of ranks, and a step of a few views per rank -- BASELINE.json config
+    3 at 8 GPUs: ~4 views against a 236 MB exchange -- does not pay for a dense Adam pass on every rank on top.  Adam is
+    element-wise, so sharding by flat index is exact: replicas stay bit-identical (every rank receives the same gathered
+    bytes).  Per-tensor learning rates (scene/gaussian_model.py:152-165) apply to the intersection of a tensor's segment
+    with the shard.
+
+    params: the tensors in FlatGrads order; grads: their FlatGrads built with multiple_of = 4 x world_size (use
+    ShardedAdam.make_buckets); lrs: one learning rate per tensor (mutable: `opt.lrs[i] = ...` follows a schedule).
+    The parameter count must not change between steps (after densification: build new buckets and a new ShardedAdam)."""
+
+    def __init__(self, params: Sequence[torch.Tensor], grads: FlatGrads, lrs: Sequence[float], betas=(0.9, 0.999),
+                 eps: float = 1e-15, adam_fn: Optional[Callable] = None):
+        self.world, self.rank = world_size(), get_rank()
+        L = grads.flat.numel()
+        if L % (4 * self.world) != 0:
+            raise ValueError("ShardedAdam: build the gradient bucket with FlatGrads(params, multiple_of=4 * world_size)")
+        self.grads, self.lrs = grads, [float(x) for x in lrs]
+        if len(self.lrs) != len(grads.segments):
+            raise ValueError("one learning rate per parameter tensor")
+        self.params = FlatParams(params, grads)
+        self.betas, self.eps, self.step_count = betas, float(eps), 0
+        self.shard = L // self.world
+        self.lo, self.hi = self.rank * self.shard, (self.rank + 1) * self.shard
+        self.grad_shard = torch.zeros(self.shard, dtype=torch.float32, device=grads.flat.device)
+        self.exp_avg = torch.zeros_like(self.grad_shard)
+        self.exp_avg_sq = torch.zeros_like(self.grad_shard)
+        self.adam_fn = adam_fn or _adam_pieces_hip
+        # (offset inside the shard, length, tensor index) of every tensor segment that meets this rank's shard
+        self.pieces = []
+        for t, (off, n) in enumerate(grads.segments):
+            a, b = max(off, self.lo), min(off + n, self.hi)
+            if a < b:
+                self.pieces.append((a - self.lo, b - a, t))
+
+    @staticmethod
+    def make_buckets(params: Sequence[torch.Tensor]) -> FlatGrads:
+        return FlatGrads(params, multiple_of=4 * world_size())
+
+    @torch.no_grad()
+    def step(self):
+        """Gradients of this rank's views are in self.grads.flat (accumulated); afterwards every rank holds the updated
+        parameters.  The bucket is left as it was (zero it before the next step: FlatGrads.zero_)."""
+        self.step_count += 1
+        flat_g, flat_p = self.grads.flat, self.params.flat
+        if self.world > 1:
+            dist.reduce_scatter_tensor(self.grad_shard, flat_g, op=dist.ReduceOp.SUM)
+            g = self.grad_shard
+        else:
+            g = flat_g
+        p_shard = flat_p[self.lo:self.hi]
+        pieces = [(p_shard[o:o + n], g[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], self.lrs[t])
+                  for o, n, t in self.pieces]
+        self.adam_fn(pieces, self.betas[0], self.betas[1], self.eps, self.step_count)
+        if self.world > 1:
+            dist.all_gather_into_tensor(flat_p, p_shard)      # in place: rank r's input IS slice r of the output
+
+
 REDUCE_CHUNKS = 2
 
 
@@ -133,9 +237,11 @@ class ChunkedViewStep:
     ORDER = ("means3D", "scales", "rotations", "opacity", "sh")
 
     def __init__(self, cams, grad_colors, named_params, sh_degree, bg, binning_capacity, n_streams=2, chunks=None,
-                 targets=None, lambda_dssim=0.2):
+                 targets=None, lambda_dssim=0.2, grads: Optional[FlatGrads] = None):
+        """grads: a bucket built by the caller over the parameters in ORDER (ShardedAdam.make_buckets pads it for the
+        reduce-scatter); default: a fresh FlatGrads."""
         self.named = {k: named_params[k] for k in self.ORDER}
-        self.grads = FlatGrads([self.named[k] for k in self.ORDER])
+        self.grads = grads if grads is not None else FlatGrads([self.named[k] for k in self.ORDER])
         n = len(cams)
         chunks = (REDUCE_CHUNKS if world_size() > 1 else 1) if chunks is None else chunks
         chunks = max(1, min(int(chunks), n))
@@ -153,17 +259,19 @@ class ChunkedViewStep:
         d["means2D"] = means2D_acc
         return d
 
-    def run(self, means2D_acc):
+    def run(self, means2D_acc, reduce: bool = True):
         """Zeroes the buckets, renders every group forward+backward into its bucket, all-reduces (overlapped) and leaves
         the sum over all ranks and views in self.grads (the parameters' .grad).  means2D_acc [P,3] accumulates the
-        screen-space gradients of THIS rank's views (densification statistics are reduced separately)."""
+        screen-space gradients of THIS rank's views (densification statistics are reduced separately).
+        reduce=False: no collective here -- self.grads holds THIS rank's sum and the exchange is the optimizer's
+        (ShardedAdam: reduce-scatter, sharded Adam, all-gather)."""
         p = self.named
         works = []
         for b in self.buckets:
             b.zero_()
         for batch, bucket in zip(self.batches, self.buckets):
             batch.run(p["means3D"], p["opacity"], p["scales"], p["rotations"], p["sh"], self._acc(bucket, means2D_acc))
-            if world_size() > 1:
+            if world_size() > 1 and reduce:
                 works.append(dist.all_reduce(bucket.flat, op=dist.ReduceOp.SUM, async_op=True))
         for w in works:
             w.wait()

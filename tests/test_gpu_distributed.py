@@ -38,6 +38,32 @@ def test_two_ranks_equal_one_rank_on_the_flat_gradient_bucket(hip_device, tmp_pa
     assert np.abs(a - want).max() <= 2e-5 * np.abs(want).max()       # same sum, different association across ranks / chunks
 
 
+def test_sharded_adam_two_ranks_equal_one_rank_with_fused_adam(hip_device, tmp_path):
+    """The strong-scaling training step on the real kernels: 8 views per step shared by 2 ranks, reduce-scatter of the
+    flat bucket, lr_adam_step on each rank's shard, all-gather of the parameters -- against ONE rank rendering all 8 views
+    and stepping optim.FusedAdam (torch.optim.Adam's arithmetic) on the whole parameters, 3 steps."""
+    from luciddreamer_amd.optim import FusedAdam
+    from tests import dist_gpu_worker as W
+    step, m2d = W.build(hip_device, 8, 1, 0, 1)
+    ordered = [step.named[k] for k in step.ORDER]
+    ref = FusedAdam([{"params": [p], "lr": lr} for p, lr in zip(ordered, W.LRS)], lr=0.0, eps=1e-15)
+    for _ in range(3):
+        step.run(m2d)
+        ref.step()
+    step.check()
+    out = str(tmp_path / "sharded.pt")
+    r = _torchrun(2, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, "sharded"], 29617)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    assert got["world"] == 2
+    flat = got["params"].numpy()
+    for p, (off, n) in zip(ordered, got["segments"]):
+        a, b = flat[off:off + n], p.detach().cpu().numpy().ravel()
+        # same Adam arithmetic on gradients that differ by float summation order across the ranks; Adam's eps = 1e-15
+        # turns a sign flip of a float-noise gradient into a +-lr step, so the bar is a few learning-rate steps
+        assert np.abs(a - b).max() <= 3 * 3 * 5e-2 * 1.001 and np.median(np.abs(a - b)) <= 1e-6, (float(np.abs(a - b).max()),)
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_runs_under_two_ranks_and_reports_the_world_size(hip_device, scaling):
     """N > 1 defaults to the stated configuration (BASELINE.json config 3): the step's views are SHARED by the ranks, one
