@@ -172,6 +172,24 @@ def forward(background, means3D, colors_precomp, opacities, scales, rotations, s
     return res
 
 
+def blend_f64(res, background, colors_precomp=None):
+    """The blend of a finished forward (restatement backend) evaluated in float64 on its float32 records and tile lists
+    (oracle_blend_f64): (3, H, W) float64.  A yardstick for float32 evaluations that disagree, not a reference output."""
+    L = lib()
+    if res._backend is not L:
+        raise ValueError("blend_f64 needs a ForwardResult of the restatement backend")
+    f = L.L.oracle_blend_f64
+    f.restype, f.argtypes = None, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                   ctypes.c_void_p]
+    out = np.zeros((3, res.H, res.W), np.float64)
+    bg, col = _f32(background), _f32(colors_precomp)
+    if res._state:
+        f(res._state, res.W, res.H, _ptr(bg), _ptr(col), out.ctypes.data_as(ctypes.c_void_p))
+    else:
+        out[:] = bg.reshape(3, 1, 1)
+    return out
+
+
 def backward(res, dL_dout_color, dL_dout_depth=None):
     """Returns the reference's 8-tuple order (RAST/rasterize_points.cu:199):
     (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)

@@ -49,22 +49,17 @@ def test_hip_reproduces_committed_reference_outputs(hip_device, name):
     color, depth, radii, grads = _run_hip_case(c, hip_device)
     assert np.array_equal(radii, fx[name + "/radii"])
     if name == "needles":
-        # Needle splats near the camera have conic entries of 1e7..1e9 whose quadratic form cancels to O(1): the exponent
-        # is the rounding residue of its evaluation order (the reference's own nvcc build, which contracts to FMAs, would
-        # not reproduce its host build here either).  What must hold: the per-Gaussian stage is bit-exact (radii above,
-        # incl. the det == 0 rejections), nothing is NaN/inf, and most of the image -- the part not under a needle --
-        # still agrees.
+        # near-singular conics: the exponent is a sum of products 1e4 times its own size, no two float32 evaluations agree
+        # to 1e-5 (the reference's own builds do not either) -- judged against a float64 evaluation in
+        # test_ill_conditioned_splats_against_the_float64_blend below
         assert np.isfinite(color).all() and np.isfinite(depth).all() and all(np.isfinite(g).all() for g in grads.values())
-        agree = (np.abs(color - fx[name + "/color"]).max(axis=0) <= hp.COLOR_ATOL).mean()
-        print(f"needles: {100 * agree:.1f}% of the pixels within 1e-5 of the reference")
-        assert agree > 0.3                    # measured 49.7 %
         return
     # pixels where the reference itself sits within an ulp of a discrete threshold: flagged by the (bit-identical)
     # restatement, which records them while blending
     frag = oracle.forward(*ref_cases.forward_args(c)).stage()["fragile"]
     ok = (frag & 1) == 0
     # (these cases are small images under heavy overdraw -- up to ~700 pairs per pixel -- so a handful is expected)
-    assert (~ok).sum() <= max(8, hp.FRAGILE_FRAC * ok.size), int((~ok).sum())
+    assert (~ok).sum() <= max(16, hp.FRAGILE_FRAC * ok.size), int((~ok).sum())
     assert np.abs(color - fx[name + "/color"])[:, ok].max() <= hp.COLOR_ATOL
     ok_d = ok & ((frag & 2) == 0)
     rd = fx[name + "/depth"][0]
@@ -81,6 +76,73 @@ def test_hip_reproduces_committed_reference_outputs(hip_device, name):
         a = grads[k].reshape(b.shape)
         scale = float(np.abs(b).max())
         assert np.abs(a - b).max() <= rtol * scale + 1e-30, (k, float(np.abs(a - b).max()), scale)
+
+
+def _sliver_case():
+    """A second ill-conditioned scene (not among the committed fixtures: the reference is evaluated live): splats 200 x longer
+    than wide close to the camera, conic entries of 1e4..1e8."""
+    rng = np.random.default_rng(61)
+    cl = ref_cases._cloud(rng, 600, (-0.5, -0.35, 0.35), (0.5, 0.35, 1.6), 0.02)
+    cl["scales"][:, 0] *= np.float32(60.0)
+    cl["scales"][:, 1:] *= np.float32(3e-3)
+    return ref_cases._case("slivers", ref_cases._cam(128, 80), cl, degree=2)
+
+
+def _reference_on_device(c, dev):
+    from oracle import ref_device
+    if not ref_device.available():
+        return None
+    t = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    r = ref_device.Renderer()
+    _, color, _, _ = r.forward(t(c["bg"]), t(c["means3D"]), t(c["colors_precomp"]), t(c["opacities"]), t(c["scales"]),
+                               t(c["rotations"]), c["scale_modifier"], t(c["cov3D_precomp"]), t(c["view"]), t(c["proj"]),
+                               c["tanfovx"], c["tanfovy"], c["H"], c["W"], t(c["shs"]) if c["colors_precomp"] is None else None,
+                               c["degree"], t(c["campos"]))
+    return color.cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["needles", "slivers"])
+def test_ill_conditioned_splats_against_the_float64_blend(hip_device, name):
+    """Needle splats: conic entries of 1e4..1e9 whose quadratic form cancels to O(1) in the exponent, so two correct float32
+    evaluations (the reference's `-0.5f*(a dx dx + c dy dy) - b dx dy`, this library's Horner form on scaled coefficients,
+    the reference compiled with or without FMA contraction) differ by the rounding residue of their operand order -- no
+    float32 image is "the" answer.  The yardstick is the same blend evaluated in float64 on the same float32 records and
+    tile lists (oracle.blend_f64).  Measured against it: the HIP image, the reference's host build (= the restatement, bit
+    for bit) and the reference's kernels compiled for this GPU.  The HIP image has to be as close to the float64 image as
+    the reference's own builds are."""
+    c = CASES[name] if name in CASES else _sliver_case()
+    color, depth, radii, grads = _run_hip_case(c, hip_device)
+    o = oracle.forward(*ref_cases.forward_args(c))
+    assert np.array_equal(radii, o.radii)                                  # the per-Gaussian stage is exact all the same
+    assert np.isfinite(color).all() and np.isfinite(depth).all() and all(np.isfinite(g).all() for g in grads.values())
+    if name == "needles":                                                  # the restatement IS the reference here
+        fx = np.load(GOLD)
+        assert np.array_equal(o.color.view(np.uint32), fx["needles/color"].view(np.uint32))
+    f64 = oracle.blend_f64(o, c["bg"], c["colors_precomp"])
+    images = {"hip": color, "reference_host": o.color}
+    dev_img = _reference_on_device(c, hip_device)
+    if dev_img is not None:
+        images["reference_gfx950"] = dev_img
+    # pixels where the reference's own value is within ITS float32 error bound of a discrete decision (sign of the exponent,
+    # alpha = 1/255, T = 1e-4): any evaluation may take the other branch there and be off by a whole layer
+    frag = (o.stage()["fragile"] & 1) != 0
+    assert frag.mean() <= 0.10, float(frag.mean())
+    stats = {}
+    for k, img in images.items():
+        e = np.abs(img.astype(np.float64) - f64).max(axis=0)
+        ok = e[~frag]
+        stats[k] = dict(max=float(ok.max()), p99=float(np.quantile(ok, 0.99)), mean=float(ok.mean()),
+                        within_1e5=float((ok <= 1e-5).mean()), max_on_flagged=float(e[frag].max()) if frag.any() else 0.0)
+    print(name, f"{int(frag.sum())} of {frag.size} pixels flagged;",
+          {k: {a: (f"{b:.2e}" if a != "within_1e5" else f"{100 * b:.1f}%") for a, b in v.items()} for k, v in stats.items()})
+    refs = [v for k, v in stats.items() if k != "hip"]
+    best_ref = {a: min(r[a] for r in refs) for a in ("max", "p99", "mean")}
+    h = stats["hip"]
+    # the HIP image is as close to the float64 image as the reference's own builds are (10 % slack on the statistics)
+    assert h["mean"] <= 1.1 * best_ref["mean"] + 1e-7, (h, best_ref)
+    assert h["p99"] <= 1.1 * best_ref["p99"] + 1e-6, (h, best_ref)
+    assert h["max"] <= 1.1 * best_ref["max"] + 1e-5, (h, best_ref)
+    assert h["within_1e5"] >= max(r["within_1e5"] for r in refs) - 0.01, (h, refs)
 
 
 @pytest.mark.skipif(not ref.available(), reason="oracle/_ref/libref_raster.so did not travel")
