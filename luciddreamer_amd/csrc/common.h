@@ -308,7 +308,11 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      uint32_t accum_mask, hipStream_t s);
+                      uint32_t accum_mask, float* acc16, hipStream_t s);
+// acc16 [P][16]: per-step interleaved accumulator of the five small gradient rows (gauss_bwd.hip); added to the caller's
+// tensors once per step
+void launch_uninterleave_add(int P, const float* acc16, float* mean2D, float* opacity, float* mean3D, float* scale, float* rot,
+                             hipStream_t s);
 // row surgery of the parameter set (rows.hip)
 size_t select_workspace_bytes(int P);
 int launch_select_rows(int P, const uint8_t* mask, int n_tensors, const void* const* src, void* const* dst,

@@ -124,7 +124,7 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-            uint32_t accum_mask)
+            uint32_t accum_mask, float* __restrict__ acc16)
 {
     const size_t i = (size_t)idx;
     const float* __restrict__ V = vp.view;
@@ -291,6 +291,20 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
         }
     }
 
+    // ---- interleaved accumulation (lr_views_accumulate): the five small rows of a Gaussian -- mean2D (2 of 3 floats),
+    // opacity, mean3D, scale, rotation: 13 floats scattered over five arrays, each a 12-16 byte read-modify-write that
+    // moves a 32-byte sector both ways -- live in ONE 64-byte row of acc16 [P][16] during the step: one full line in, one
+    // out.  k_uninterleave_add hands them to the caller's tensors once per step.
+    if (acc16 != nullptr) {
+        float4* row = reinterpret_cast<float4*>(acc16 + 16 * i);
+        float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+        r0.x += o_m2d[0]; r0.y += o_m2d[1]; r0.z += o_op; r0.w += o_m3d[0];
+        r1.x += o_m3d[1]; r1.y += o_m3d[2]; r1.z += o_scale[0]; r1.w += o_scale[1];
+        r2.x += o_scale[2]; r2.y += o_rot[0]; r2.z += o_rot[1]; r2.w += o_rot[2];
+        r3.x += o_rot[3];
+        row[0] = r0; row[1] = r1; row[2] = r2; row[3] = r3;
+        return;
+    }
     // ---- store (or accumulate) the rows of this visible Gaussian ----
 #define LR_OUT(bit, ptr, val) do { float* p__ = (ptr); *p__ = ((accum_mask >> (bit)) & 1u) ? (*p__ + (val)) : (val); } while (0)
     LR_OUT(ACC_MEAN2D, dL_dmean2D + 3 * i, o_m2d[0]); LR_OUT(ACC_MEAN2D, dL_dmean2D + 3 * i + 1, o_m2d[1]);
@@ -348,7 +362,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-            uint32_t accum_mask)
+            uint32_t accum_mask, float* __restrict__ acc16)
 {
     constexpr uint32_t SERIAL_MAX = 24;      // instances summed by the owning lane; more -> whole wave helps
     constexpr int BST = 17;                  // LDS row stride (floats) of the per-Gaussian basis rows: odd -> no conflicts
@@ -495,7 +509,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         if (live)
             gauss_backward_one<RAW>(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
                                dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale,
-                               dL_drot, accum_mask);
+                               dL_drot, accum_mask, acc16);
         __syncthreads();                     // the LDS planes are rewritten by the next round
     }
 }
@@ -554,7 +568,7 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      uint32_t accum_mask, hipStream_t s)
+                      uint32_t accum_mask, float* acc16, hipStream_t s)
 {
     (void)colors_precomp;
     if (vp.P <= 0) return;
@@ -562,11 +576,46 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
     if (vp.raw)
         hipLaunchKernelGGL(k_gauss_bwd<true>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
                            cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
     else
         hipLaunchKernelGGL(k_gauss_bwd<false>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
                            cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask);
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
+}
+
+namespace {
+// acc16 [P][16] -> the caller's accumulators (lr_views_accumulate, once per step): rows that no view touched are all
+// zero and are skipped (nothing read or written on the caller's side)
+__global__ void __launch_bounds__(256)
+k_uninterleave_add(int P, const float* __restrict__ acc16, float* __restrict__ mean2D, float* __restrict__ opacity,
+                   float* __restrict__ mean3D, float* __restrict__ scale, float* __restrict__ rot)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= P) return;
+    const float4* row = reinterpret_cast<const float4*>(acc16 + 16 * (size_t)i);
+    const float4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    const bool any = r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f || r1.z != 0.f ||
+                     r1.w != 0.f || r2.x != 0.f || r2.y != 0.f || r2.z != 0.f || r2.w != 0.f || r3.x != 0.f;
+    if (!any) return;
+    const size_t k = (size_t)i;
+    mean2D[3 * k] += r0.x; mean2D[3 * k + 1] += r0.y;
+    opacity[k] += r0.z;
+    mean3D[3 * k] += r0.w; mean3D[3 * k + 1] += r1.x; mean3D[3 * k + 2] += r1.y;
+    if (scale != nullptr) { scale[3 * k] += r1.z; scale[3 * k + 1] += r1.w; scale[3 * k + 2] += r2.x; }
+    if (rot != nullptr) {
+        float4* pr = reinterpret_cast<float4*>(rot) + i;
+        float4 v = *pr;
+        v.x += r2.y; v.y += r2.z; v.z += r2.w; v.w += r3.x;
+        *pr = v;
+    }
+}
+}  // namespace
+
+void launch_uninterleave_add(int P, const float* acc16, float* mean2D, float* opacity, float* mean3D, float* scale, float* rot,
+                             hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(k_uninterleave_add, dim3((P + 255) / 256), dim3(256), 0, s, P, acc16, mean2D, opacity, mean3D, scale, rot);
 }
 
 }  // namespace lr

@@ -87,7 +87,7 @@ def compare_forward(hip, ref, check_exact=True, max_fragile=None):
     n_pix = frag.size
     frag_c = (frag & 1) != 0
     frag_d = (frag & 2) != 0
-    allowed = max(2, FRAGILE_FRAC * n_pix) if max_fragile is None else max_fragile
+    allowed = max(8, FRAGILE_FRAC * n_pix) if max_fragile is None else max_fragile      # small images under heavy overdraw
     assert frag_c.sum() <= allowed, f"too many threshold-fragile pixels: {frag_c.sum()}"
     if check_exact:
         assert np.array_equal(hip["radii"], ref["radii"]), \

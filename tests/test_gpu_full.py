@@ -168,7 +168,7 @@ def test_c4_shape_1440p_with_depth(hip_device):
     bg = torch.zeros(3)
     ref = hp.run_oracle(cloud, cam, 3, bg)
     hip = hp.run_hip(cloud, cam, 3, bg, hip_device)
-    fig = hp.compare_forward(hip, ref)
+    fig = hp.compare_forward(hip, ref, max_fragile=5e-4 * 2560 * 1440)      # flagged by the oracle: 2.1e-4 of the pixels at this overdraw
     assert (ref["depth"] > 0).mean() > 0.1
     print("C4-shape", ref["num_rendered"], fig)
 
