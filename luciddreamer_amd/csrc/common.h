@@ -95,7 +95,7 @@ PartPlan part_plan(int num_tiles);
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, goff, vis_list, total;
+    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, vis_list, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -105,7 +105,6 @@ inline GeomLayout geom_layout(int P) {
     L.tiles_touched = o; o += align_up(Pz * 4);      // instances each Gaussian emits (after exact tile culling)
     L.vis_list = o;      o += align_up(Pz * 4);      // ids of the emitting Gaussians, index order (num_compact entries)
     L.offsets = o;       o += align_up(Pz * 4);      // first instance slot of vis_list[k]
-    L.goff = o;          o += align_up(Pz * 4);      // the same, indexed by Gaussian id
     L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 16);
     L.total = o;
     return L;
@@ -252,11 +251,11 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
                       uint32_t** keys_out, uint32_t** vals_out, hipStream_t s);
 
 // Order-preserving compaction of the Gaussians with tiles_touched != 0 (vis_list) fused with the exclusive scan of their
-// instance counts (offsets by rank, goff by Gaussian id); fills every count of the header: num_compact, num_rendered
+// instance counts (offsets, by rank: the per-Gaussian backward reads first slot and count from it); fills every count of the header: num_compact, num_rendered
 // (the reference's: sum of the tile-rectangle areas over all Gaussians), num_instances, num_sorted, overflow, bin_bound.
 // block_sums: per SCAN_TILE chunk {emitting Gaussians, instances, rectangle areas, -}, accumulated by k_preprocess.
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
-                    uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s);
+                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, hipStream_t s);
 // optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
 struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };
 // count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1
@@ -304,8 +303,8 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
                        hipStream_t s);
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* tiles_touched,
-                      const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
+                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,
+                      const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, float* acc16, hipStream_t s);

@@ -357,8 +357,8 @@ __global__ void __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
             const float* __restrict__ cov3D_precomp, const uint32_t* __restrict__ vis_list,
-            const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ tiles_touched,
-            const uint32_t* __restrict__ goff, const char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr,
+            const uint8_t* __restrict__ clamped, const uint32_t* __restrict__ offsets,
+            const char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr,
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
@@ -385,8 +385,11 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         const bool live = t < n;
         const int idx = live ? (int)vis_list[t] : 0;
         s_idx[lane] = (uint32_t)idx;
-        const uint32_t tt = live ? tiles_touched[idx] : 0u;
-        const uint32_t off = live ? goff[idx] : 0u;
+        // first instance slot and instance count from the rank-ordered `offsets` (dense reads: neighbouring lanes read
+        // neighbouring words) instead of goff[idx] / tiles_touched[idx] -- two more 64-byte lines per visible Gaussian for
+        // 4 useful bytes each when ~9 % of the Gaussians are visible
+        const uint32_t off = live ? offsets[t] : 0u;
+        const uint32_t tt = live ? ((t + 1 < n) ? offsets[t + 1] : hdr->num_instances) - off : 0u;
         float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0, g2 = g0;
         if (tt <= SERIAL_MAX && off < n_slots) {
             // four slots per step with independent loads (a one-slot loop pays one memory latency per instance)
@@ -564,8 +567,8 @@ void launch_zero_outputs(float* const* ptrs, const unsigned long long* nfloats, 
 
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
-                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* tiles_touched,
-                      const uint32_t* goff, const char* bin_base, const GeomHeader* hdr,
+                      const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,
+                      const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                       uint32_t accum_mask, float* acc16, hipStream_t s)
@@ -575,11 +578,11 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
     const int groups = std::min((vp.P + GB_THREADS - 1) / GB_THREADS, GB_MAX_GROUPS);
     if (vp.raw)
         hipLaunchKernelGGL(k_gauss_bwd<true>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
-                           cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
+                           cov3D_precomp, vis_list, clamped, offsets, bin_base, hdr, dL_dmean2D, dL_dconic,
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
     else
         hipLaunchKernelGGL(k_gauss_bwd<false>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
-                           cov3D_precomp, vis_list, clamped, tiles_touched, goff, bin_base, hdr, dL_dmean2D, dL_dconic,
+                           cov3D_precomp, vis_list, clamped, offsets, bin_base, hdr, dL_dmean2D, dL_dconic,
                            dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
 }
 

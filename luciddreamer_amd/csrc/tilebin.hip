@@ -10,7 +10,7 @@
 // in depth order and stably partitioned by tile with 2 more: 21 launches, 0.19 ms per C3 view for ~47 MB of bytes):
 //
 //   k_compact_write (chunk sums: k_preprocess)   one scan over the P Gaussians gives, in INDEX order, the list of emitting
-//                                        Gaussians (vis_list), each one's first instance slot (offsets / goff) and
+//                                        Gaussians (vis_list), each one's first instance slot (offsets, by rank) and
 //                                        every count of the header.  Instance slots are therefore contiguous per
 //                                        Gaussian and ascending with the Gaussian index.
 //   k_part<COUNT>                        a few hundred large workgroups each walk a contiguous chunk of vis_list, run the
@@ -63,8 +63,7 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 // -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
-                uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, uint32_t* __restrict__ goff,
-                GeomHeader* hdr)
+                uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, GeomHeader* hdr)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_wc[4], s_wi[4];
@@ -107,7 +106,6 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
         if (tt[i]) {
             vis_list[run_c] = (uint32_t)(base + i);
             offsets[run_c] = run_i;
-            goff[base + i] = run_i;            // where this Gaussian's instance slots start
             run_c++;
             run_i += tt[i];
         }
@@ -625,11 +623,11 @@ PartPlan part_plan(int num_tiles)
 }
 
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
-                    uint32_t* vis_list, uint32_t* offsets, uint32_t* goff, GeomHeader* hdr, hipStream_t s)
+                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
-                       offsets, goff, hdr);
+                       offsets, hdr);
 }
 
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
