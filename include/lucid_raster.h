@@ -358,6 +358,15 @@ int lr_check(const char* geom_buffer, long long* num_rendered, void* stream);
  * out8) returns 1 and fills out8 once the copy has completed (the ticket is then released), 0 if it has not and
  * block == 0, a negative LR_ERR_* on a bad ticket.  The device current at lr_header_post must be the buffer's. */
 long long lr_header_post(const char* geom_buffer, void* stream);
+/* "Verify in the forward": lr_request_early_header() makes the next async-mode lr_forward / lr_forward_raw on the calling
+ * thread post such a ticket itself as soon as the view's counts are final -- after the compaction scan, with the binning and
+ * blend kernels enqueued behind it -- and lr_take_early_ticket() hands it out (-1: none, e.g. exact mode or P == 0).  A caller
+ * that polls it with block = 1 right after lr_forward returns waits only for the preprocess and scan kernels (the host has
+ * enqueued the rest of the forward meanwhile, so the GPU does not idle as it does during exact mode's read-back) and knows
+ * before it hands the image to anyone whether the view overflowed; if so it calls lr_forward again with binning_capacity = 0.
+ * The Python operator's default policy. */
+void lr_request_early_header(void);
+long long lr_take_early_ticket(void);
 int lr_header_poll(long long ticket, int block, unsigned int* out8);
 
 /* Optional per-stage timing with HIP events recorded on the call's stream (bench.py roofline leg).

@@ -90,6 +90,16 @@ mark_visible = _C_ext.mark_visible
 check = _C_ext.check
 
 
+def request_early_header():
+    """The next async-mode forward on this thread posts a header ticket right after its compaction scan (lr_request_early_header)."""
+    _C_ext.request_early_header()
+
+
+def take_early_ticket():
+    """Ticket of that early header copy, or -1."""
+    return _C_ext.take_early_ticket()
+
+
 def header_post(geomBuffer):
     """Non-blocking read-back of a forward's header on the current stream (lr_header_post); returns a ticket."""
     return _C_ext.header_post(geomBuffer)

@@ -344,6 +344,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("mark_visible", &mark_visible);
     m.def("check", &check);
     m.def("header_post", &header_post);
+    m.def("request_early_header", [] { lr_request_early_header(); });
+    m.def("take_early_ticket", [] { return (int64_t)lr_take_early_ticket(); });
     m.def("header_poll", &header_poll);
     m.def("version", [] { return std::string(lr_version()); });
 }

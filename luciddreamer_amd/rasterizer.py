@@ -42,23 +42,30 @@ class _RasterizeGaussians(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
-                raster_settings, differentiable=True):
+                raster_settings):
         rs = raster_settings
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
                 rs.sh_degree, rs.campos, rs.prefiltered, rs.debug)
-        # async mode only for forwards that will be differentiated (a backward can repair an overflowed view; nothing can
-        # repair a frame of a render-only loop): `differentiable` is evaluated by the caller, where grad mode is visible
-        capacity = config.capacity_for(means3D, rs, differentiable)
+        capacity = config.capacity_for(means3D, rs)
+        verifying = config.verifying(capacity)
         try:
+            if verifying:
+                _C.request_early_header()
             num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
                 *args, binning_capacity=capacity)
+            # policy "verify": every kernel of the forward is enqueued; wait for the copy of the header the library posted
+            # after the scan, and if the view needs more instances than the buffer holds render it again in exact mode --
+            # what is returned is always a complete image
+            if verifying and config.verify(means3D, rs, _C.take_early_ticket()):
+                capacity = 0
+                num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(*args, binning_capacity=0)
         except Exception:
             if rs.debug:
                 _snapshot(args, "snapshot_fw.dump")
                 print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
             raise
-        ctx.ticket, ctx.owner = config.note_forward(means3D, rs, num_rendered, geom, capacity) or (None, None)
+        config.note_forward(means3D, rs, num_rendered, geom, capacity)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.binning_capacity = capacity
@@ -66,15 +73,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.leaf_inputs = dict(means3D=means3D, means2D=means2D, sh=sh, colors=colors_precomp, opacity=opacities,
                                scales=scales, rotations=rotations, cov3D=cov3Ds_precomp) \
             if config.fused_grad_accumulation() else None
-        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img,
-                              opacities)
+        ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img)
         return color, radii, depth
 
     @staticmethod
     def backward(ctx, grad_out_color, grad_radii, grad_depth):
         rs = ctx.raster_settings
-        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img, opacities = \
-            ctx.saved_tensors
+        colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning, img = ctx.saved_tensors
         if grad_out_color is None:
             grad_out_color = torch.zeros((3, rs.image_height, rs.image_width), dtype=torch.float32, device=means3D.device)
         args = (rs.bg, means3D, radii, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -89,22 +94,9 @@ class _RasterizeGaussians(torch.autograd.Function):
                         and g.data_ptr() % 16 == 0:      # the kernels accumulate with 16-byte accesses; else: dense path
                     accumulate_into[name] = g
         try:
-            grads = _C.rasterize_gaussians_backward(
-                *args, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into, skip_unused=True)
-            # Async forward under the "rerender" policy: the kernels just enqueued skip themselves if the view overflowed
-            # its buffer (zero gradients / nothing accumulated).  Only NOW wait for the forward's header -- the GPU has
-            # the backward queued behind the forward, so it does not idle while the host waits -- and if the view did
-            # overflow, render it again in exact mode and differentiate that render instead.
-            if ctx.ticket is not None and config.claim(ctx.ticket):
-                num_rendered, _c, _d, radii2, geom2, binning2, img2 = _C.rasterize_gaussians(
-                    rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
-                    rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
-                    rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, binning_capacity=0)
-                args = args[:2] + (radii2,) + args[3:17] + (geom2, num_rendered, binning2, img2, rs.debug)
-                grads = _C.rasterize_gaussians_backward(*args, binning_capacity=0, accumulate_into=accumulate_into,
-                                                        skip_unused=True)
             (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh,
-             grad_scales, grad_rotations) = grads
+             grad_scales, grad_rotations) = _C.rasterize_gaussians_backward(
+                *args, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into, skip_unused=True)
         except Exception:
             if rs.debug:
                 _snapshot(args, "snapshot_bw.dump")
@@ -112,19 +104,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             raise
         # order of the forward inputs (RAST/.../__init__.py:144-154); gradients of absent inputs are None-able
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, None, None)
-
-
-def _will_be_differentiated(*tensors):
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+                grad_cov3Ds_precomp, None)
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings,
-                                     _will_be_differentiated(means3D, means2D, sh, colors_precomp, opacities, scales,
-                                                             rotations, cov3Ds_precomp))
+                                     cov3Ds_precomp, raster_settings)
 
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):
@@ -132,15 +118,23 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
     exp / normalize / sigmoid / cat and their autograd nodes (R/scene/gaussian_model.py:97-117)."""
 
     @staticmethod
-    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings,
-                differentiable=True):
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
         rs = raster_settings
-        capacity = config.capacity_for(xyz, rs, differentiable)
-        num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians_raw(
-            rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
-            rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug,
-            binning_capacity=capacity)
-        ctx.ticket, ctx.owner = config.note_forward(xyz, rs, num_rendered, geom, capacity) or (None, None)
+        capacity = config.capacity_for(xyz, rs)
+        verifying = config.verifying(capacity)
+
+        def run(cap):
+            return _C.rasterize_gaussians_raw(
+                rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
+                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug,
+                binning_capacity=cap)
+        if verifying:
+            _C.request_early_header()
+        num_rendered, color, depth, radii, geom, binning, img = run(capacity)
+        if verifying and config.verify(xyz, rs, _C.take_early_ticket()):       # overflowed: an exact-mode render instead
+            capacity = 0
+            num_rendered, color, depth, radii, geom, binning, img = run(0)
+        config.note_forward(xyz, rs, num_rendered, geom, capacity)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.binning_capacity = capacity
@@ -168,28 +162,18 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_dc, g_rest = leaf_grad(li["features_dc"]), leaf_grad(li["features_rest"])
             if g_dc is not None and (g_rest is not None or features_rest.numel() == 0):
                 accumulate_into["features"] = (g_dc, g_rest)
-        def run(radii_, geom_, num_rendered_, binning_, img_, capacity_):
-            return _C.rasterize_gaussians_raw_backward(
-                rs.bg, xyz, radii_, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
-                rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom_, num_rendered_,
-                binning_, img_, rs.debug, binning_capacity=capacity_, accumulate_into=accumulate_into)
-        g = run(radii, geom, ctx.num_rendered, binning, img, ctx.binning_capacity)
-        if ctx.ticket is not None and config.claim(ctx.ticket):          # overflowed (the kernels above skipped themselves):
-            num_rendered, _c, _d, radii2, geom2, binning2, img2 = _C.rasterize_gaussians_raw(    # an exact-mode render instead
-                rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
-                rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug,
-                binning_capacity=0)
-            g = run(radii2, geom2, num_rendered, binning2, img2, 0)
+        g = _C.rasterize_gaussians_raw_backward(
+            rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
+            rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
+            binning, img, rs.debug, binning_capacity=ctx.binning_capacity, accumulate_into=accumulate_into)
         g_means2D, g_xyz, g_dc, g_rest, g_op, g_sc, g_rot = g
-        return g_xyz, g_means2D, g_dc, g_rest, g_op, g_sc, g_rot, None, None
+        return g_xyz, g_means2D, g_dc, g_rest, g_op, g_sc, g_rot, None
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation, raster_settings):
     """(color, radii, depth) from the stored GaussianModel parameters (pre-activation), see _RasterizeGaussiansRaw."""
     return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
-                                        raster_settings,
-                                        _will_be_differentiated(xyz, means2D, features_dc, features_rest, opacity, scaling,
-                                                                rotation))
+                                        raster_settings)
 
 
 class GaussianRasterizer(nn.Module):

@@ -41,7 +41,7 @@ def run_oracle(cloud, cam, degree, bg, grad_color=None, colors_precomp=None, cov
 
 
 def run_hip(cloud, cam, degree, bg, device, grad_color=None, colors_precomp=None, cov3D_precomp=None,
-            scale_modifier=1.0, use_sh=True, prefiltered=False, debug=False, grad_depth=None, sync_before_backward=False):
+            scale_modifier=1.0, use_sh=True, prefiltered=False, debug=False, grad_depth=None):
     """Through depth_diff_gaussian_rasterization_min's public API (autograd op -> _C -> C-ABI)."""
     from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
     tfx, tfy = tan_fov(cam)
@@ -65,8 +65,6 @@ def run_hip(cloud, cam, degree, bg, device, grad_color=None, colors_precomp=None
                radii=radii.detach().cpu().numpy(), color_t=color, depth_t=depth)
     if grad_color is not None:
         loss = (color * grad_color.to(device)).sum()
-        if sync_before_backward:          # a host-bound loop: the forward has finished by the time backward() runs
-            torch.cuda.synchronize()
         if grad_depth is not None:
             loss = loss + (depth * grad_depth.to(device)).sum()
         loss.backward()

@@ -1,5 +1,5 @@
 """CPU: the host logic of async mode (luciddreamer_amd.config) -- high-water mark, warm calls, the overflow policies
-("rerender": the backward claims its forward's header; "drop" / "raise": deferred check over header tickets) -- with the
+("verify": the forward waits for its own early header; "drop" / "raise": deferred check over header tickets) -- with the
 binding's two ticket functions replaced by a fake that
 completes read-backs on demand.  The real lr_header_post / lr_header_poll are exercised on the GPU
 (tests/test_gpu_parity.py::test_header_tickets)."""
@@ -60,12 +60,12 @@ def _header(num_rendered, overflow=0, trap=0, instances=None):
     return [num_rendered, overflow, trap, 0, 0, inst, inst, 0]
 
 
-def test_defaults_are_async_with_rerender_and_two_warm_calls():
+def test_defaults_are_async_with_verify_and_two_warm_calls():
     import importlib
     import os
     assert os.environ.get("LUCID_RASTER_EXACT", "0") != "1"
     mod = importlib.reload(config)
-    assert mod.is_async() and mod.current_policy() == "rerender" and mod._warm_calls == 2
+    assert mod.is_async() and mod.current_policy() == "verify" and mod._warm_calls == 2
 
 
 def test_exact_until_a_mark_exists_then_capacity_from_the_mark(fake):
@@ -78,46 +78,27 @@ def test_exact_until_a_mark_exists_then_capacity_from_the_mark(fake):
     assert fake.next == 0
     cap = config.capacity_for(means, rs)
     assert cap == int(10_000 * 1.5) + 4096
-    assert config.capacity_for(means, rs, differentiable=False) == 0      # no backward will follow: exact (render-only loops)
     assert config.capacity_for(torch.zeros(0, 3), rs) == 0          # empty cloud: nothing to size
     assert config.capacity_for(torch.zeros(1000, 3), _rs(32, 32)) == 0      # another (P, H, W): its own first sighting
 
 
-def test_rerender_policy_the_backward_claims_its_header(fake):
+def test_verify_policy_the_forward_waits_for_its_own_header(fake):
     means, rs = torch.zeros(500, 3), _rs()
-    config.set_async(True, headroom=1.0, warm_calls=1, wait=True)    # on_overflow="rerender" is the default; strict form
+    config.set_async(True, headroom=1.0, warm_calls=1)               # on_overflow="verify" is the default
     config.note_forward(means, rs, 1_000, None, 0)
     cap = config.capacity_for(means, rs)
-    t_ok, own_ok = config.note_forward(means, rs, -1, _header(900), cap)
-    t_over, own_over = config.note_forward(means, rs, -1, _header(50_000, overflow=1), cap)
-    assert fake.next == 2 and len(config._pending) == 2
-    config.capacity_for(means, rs)                                   # a poll in between leaves owned tickets alone
-    assert len(config._pending) == 2 and not fake.polled
-    assert config.claim(t_over) is True                              # blocks on ITS ticket only; overflowed -> re-render
-    assert fake.polled == [(t_over, True)]
+    assert config.verifying(cap) and not config.verifying(0)
+    t_ok = fake.header_post(_header(900))                            # what lr_forward posts after its compaction scan
+    assert config.verify(means, rs, t_ok) is False and fake.polled[-1] == (t_ok, True)      # blocks on ITS ticket
+    t_over = fake.header_post(_header(50_000, overflow=1))
+    assert config.verify(means, rs, t_over) is True                  # overflowed: the caller renders again in exact mode
     assert config.rerendered_views == 1 and config.dropped_views == 0
     assert config.capacity_for(means, rs) == 50_000 + 4096            # the mark follows the true count
-    assert config.claim(t_ok) is False
+    assert config.verify(means, rs, -1) is False                     # no ticket (exact mode, empty cloud)
+    config.note_forward(means, rs, -1, _header(10), cap)             # "verify" posts nothing afterwards
     assert not config._pending
-    assert config.claim(t_ok) is False                               # claimed twice: nothing to do
-    # default form (wait=False): a header that has not arrived is not waited for -- the ticket goes to the deferred check
-    config.set_async(True, headroom=1.0, warm_calls=1)
-    t4, own4 = config.note_forward(means, rs, -1, _header(60_000, overflow=1), cap)
-    assert config.claim(t4) is False and fake.polled[-1] == (t4, False) and len(config._pending) == 1
-    fake.complete(t4)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        config.drain()
-    assert any("ZERO" in str(x.message) for x in w) and config.dropped_views == 1
-    t5, own5 = config.note_forward(means, rs, -1, _header(70_000, overflow=1), cap)
-    fake.complete(t5)                                                # ... and one that has arrived is acted upon
-    assert config.claim(t5) is True and config.rerendered_views == 2
-    # a forward whose graph is released without a backward: the ticket falls to the deferred poll
-    t3, own3 = config.note_forward(means, rs, -1, _header(700), cap)
-    del own3
-    fake.complete(t3)
-    config.drain()
-    assert not config._pending
+    with config.overflow_policy("drop"):
+        assert not config.verifying(cap)
 
 
 def test_deferred_check_polls_in_order_and_raises_the_mark(fake):
@@ -125,7 +106,7 @@ def test_deferred_check_polls_in_order_and_raises_the_mark(fake):
     config.set_async(True, headroom=1.2, warm_calls=1, on_overflow="drop")
     config.note_forward(means, rs, 5_000, None, 0)
     cap = config.capacity_for(means, rs)
-    assert config.note_forward(means, rs, -1, _header(7_000, instances=6_500), cap) is None    # a ticket, nothing blocks
+    config.note_forward(means, rs, -1, _header(7_000, instances=6_500), cap)    # async forward: a ticket, nothing blocks
     config.note_forward(means, rs, -1, _header(6_000, instances=5_500), cap)
     assert fake.next == 2 and len(config._pending) == 2
     config.capacity_for(means, rs)                                   # polls: nothing has completed
@@ -162,11 +143,11 @@ def test_deferred_overflow_policies(fake):
         config.set_async(True, on_overflow="warn")                   # the round-2 policy (train on truncated gradients) is gone
     # a temporary policy (what parallel.ViewStreams does around its views)
     config.set_async(True, warm_calls=1)
-    assert config.current_policy() == "rerender"
+    assert config.current_policy() == "verify"
     with config.overflow_policy("drop"):
         assert config.current_policy() == "drop"
-        assert config.note_forward(means, rs, -1, _header(10), cap) is None
-    assert config.current_policy() == "rerender"
+        config.note_forward(means, rs, -1, _header(10), cap)
+    assert config.current_policy() == "verify" and len(config._pending) == 1
     fake.complete(*range(fake.next))
     config.drain()
 

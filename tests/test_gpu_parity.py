@@ -238,10 +238,11 @@ def test_header_tickets(hip_device):
 
 
 def test_async_mode_warm_calls_and_overflow_policies(hip_device):
-    """warm_calls exact forwards feed the high-water mark.  A view that overflows its async-mode buffer is never
-    differentiated as it is: with the default policy ("rerender") the backward renders it again in exact mode and the
-    caller gets EXACT-MODE GRADIENTS; with "drop" / "raise" (nothing waits) its gradients are zero -- the backward kernels
-    skip it on the device -- and the deferred check warns / raises.  The capacity is raised either way."""
+    """warm_calls exact forwards feed the high-water mark.  A view that overflows its async-mode buffer is never handed out or
+    differentiated as it is: with the default policy ("verify") the forward waits for the header copy the library posts after
+    the scan and renders the view again in exact mode -- image AND gradients are exact mode's, with or without a backward;
+    with "drop" / "raise" (nothing waits) the image is incomplete, the gradients are zero -- the backward kernels skip the
+    view on the device -- and the deferred check warns / raises.  The capacity is raised either way."""
     import warnings
     from luciddreamer_amd import config
     cloud = synthetic.make_cloud(120_000, "band", 4)          # ~20 k tile instances per view: well above the +4096 slack
@@ -262,33 +263,31 @@ def test_async_mode_warm_calls_and_overflow_policies(hip_device):
             assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["color"], c["color"])
             for k in a["grads"]:
                 assert np.array_equal(a["grads"][k], c["grads"][k]), k
-        # shrink the mark artificially: the next view overflows.  Default policy: re-rendered inside its backward (strict
-        # form: wait for the header; the default polls, and this test's host is far ahead of the GPU)
-        config.set_async(True, headroom=1.0, warm_calls=1, wait=True)
+        # shrink the mark artificially: the next view overflows.  Default policy: caught inside the forward
+        config.set_async(True, headroom=1.0, warm_calls=1)
         config._hwm[key] = 64
         before = config.rerendered_views
         over = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
         assert config.rerendered_views == before + 1
-        assert not np.array_equal(over["color"], exact[0]["color"])                # the image it got WAS incomplete ...
-        for k in exact[0]["grads"]:                                                # ... the gradients are exact mode's
-            assert np.array_equal(over["grads"][k], exact[0]["grads"][k]), k
-        assert config._hwm[key] > 64                                               # raised from the true count
-        again = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
-        config.drain()
-        assert np.array_equal(again["color"], exact[0]["color"])
-        # the default form polls instead of waiting: when the forward has finished by the time backward() runs (a loop
-        # whose host is the bottleneck, like the reference's) the overflow is known and the view is re-rendered as well
-        config.set_async(True, headroom=1.0, warm_calls=1)
-        config._hwm[key] = 64
-        before = config.rerendered_views
-        over = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g, sync_before_backward=True)
-        assert config.rerendered_views == before + 1
+        assert np.array_equal(over["color"], exact[0]["color"]) and np.array_equal(over["depth"], exact[0]["depth"])
         for k in exact[0]["grads"]:
             assert np.array_equal(over["grads"][k], exact[0]["grads"][k]), k
+        assert config._hwm[key] > 64                                               # raised from the true count
+        # ... also when no backward follows and grad mode is on, as in the reference's video loop
+        config._hwm[key] = 64
+        frame = hp.run_hip(cloud, cams[1], 3, bg, hip_device)
+        assert np.array_equal(frame["color"], exact[1]["color"])
+        with torch.no_grad():
+            config._hwm[key] = 64
+            frame = hp.run_hip(cloud, cams[2], 3, bg, hip_device)
+        assert np.array_equal(frame["color"], exact[2]["color"])
+        again = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)                   # enough capacity again: async, complete
+        assert np.array_equal(again["color"], exact[0]["color"])
         # "drop": nothing waits; the overflowed view's gradients are ZERO (never truncated ones), a warning follows
         config.set_async(True, headroom=1.0, warm_calls=1, on_overflow="drop")
         config._hwm[key] = 64
         dropped = hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
+        assert not np.array_equal(dropped["color"], exact[0]["color"])             # the image it got WAS incomplete
         for k, v in dropped["grads"].items():
             assert float(np.abs(v).max()) == 0.0, k
         with warnings.catch_warnings(record=True) as w:
@@ -301,12 +300,6 @@ def test_async_mode_warm_calls_and_overflow_policies(hip_device):
         hp.run_hip(cloud, cams[0], 3, bg, hip_device, g)
         with pytest.raises(RuntimeError, match="capacity"):
             config.drain()
-        # a forward that will not be differentiated stays exact whatever the mark says
-        config.set_async(True, headroom=1.0, warm_calls=1)
-        config._hwm[key] = 64
-        with torch.no_grad():
-            frame = hp.run_hip(cloud, cams[0], 3, bg, hip_device)
-        assert np.array_equal(frame["color"], exact[0]["color"])
     finally:
         config.set_async(True)
         config.reset()
