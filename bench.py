@@ -397,10 +397,27 @@ def main():
             v, ms, host, _ = run_leg(wl, api, exact, args.streams, args.steps, args.warmup, world, dev, fused)
             entry_points[key] = round(v, 1)
             entry_points[key.replace("_views_per_s", "_host_issue_ms_per_step")] = round(host, 3)
+        # the forward-only path of the video renderer (R/luciddreamer.py:250-255: render() per frame, grad mode on, no
+        # backward), default configuration, frames left on the device
+        from luciddreamer_amd import config
+        config.reset()
+        config.set_async(True)
+
+        def frames():
+            for r in wl.rasterizers:
+                r(means3D=wl.leaf["means3D"], means2D=wl.means2D, opacities=wl.leaf["opacities"], shs=wl.leaf["shs"],
+                  scales=wl.leaf["scales"], rotations=wl.leaf["rotations"])
+        for _ in range(args.warmup):
+            frames()
+        dt, host = timed(frames, args.steps, world, dev)
+        entry_points["render_only_views_per_s"] = round(wl.total_views * args.steps / dt, 1)
+        entry_points["render_only_host_issue_ms_per_step"] = round(host, 3)
+        config.reset()
         entry_points["note"] = ("drop_in: GaussianRasterizer autograd op per view (the reference's API) with the library's "
                                 f"default configuration (no config call), views pipelined over {args.streams} streams "
                                 "(parallel.ViewStreams); exact_mode: the same with the reference's host round trip per view; "
-                                "views_loss: the headline step with the fused L1+DSSIM loss formed inside")
+                                "views_loss: the headline step with the fused L1+DSSIM loss formed inside; render_only: forward "
+                                "only, one stream, default configuration (the video renderer's loop)")
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = run_cpu_baseline(wl)

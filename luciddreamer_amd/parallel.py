@@ -323,7 +323,7 @@ class ViewStreams:
             s.wait_stream(cur)
         self._prev_bwd = None
         self._caller = cur
-        # several views in flight: a backward must not wait for its forward's header copy (config "rerender" does); an
+        # several views in flight: a forward must not wait for its own header copy (config "verify" does); an
         # overflowed view contributes zero gradients and is reported by the deferred check instead
         config._override.append("drop")
         self._policy_pushed = True
