@@ -30,6 +30,18 @@ struct __attribute__((aligned(16))) GradRec {
 };
 static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 
+// What the binning needs of an emitting Gaussian, in one 16-byte gather: the result of preprocess's exact tile test as a
+// bit mask over its tile rectangle (bit j = tile (miny + j / rw, minx + j % rw) passes; rectangles of up to HIT_MASK_TILES
+// tiles), the rectangle's origin and width, and the depth bits of the sort word.  The count and scatter passes of the binning
+// walk the set bits instead of repeating the ~45-instruction test per tile (it used to run three times per pair).
+//   x, y : mask bits 0-31, 32-63      z : minx | miny << 12 | rw << 24, or 0 = no mask (larger rectangle, or a tile grid
+//   w    : view depth as uint32                                               beyond 4096: the walk tests / emits from the record)
+constexpr uint32_t HIT_MASK_TILES = 64;
+__host__ __device__ inline uint32_t hit_geo(int minx, int miny, int rw, uint32_t area)
+{
+    return (area <= HIT_MASK_TILES && minx < 4096 && miny < 4096) ? ((uint32_t)minx | ((uint32_t)miny << 12) | ((uint32_t)rw << 24)) : 0u;
+}
+
 // Header at offset 0 of the geom buffer (device-resident view state).
 struct GeomHeader {
     uint32_t num_rendered;          // the reference's num_rendered: sum of tile-rectangle areas (reported to callers)
@@ -95,7 +107,7 @@ PartPlan part_plan(int num_tiles);
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, vis_list, total;
+    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, vis_list, hitrec, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -106,6 +118,7 @@ inline GeomLayout geom_layout(int P) {
     L.vis_list = o;      o += align_up(Pz * 4);      // ids of the emitting Gaussians, index order (num_compact entries)
     L.offsets = o;       o += align_up(Pz * 4);      // first instance slot of vis_list[k]
     L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 16);
+    L.hitrec = o;        o += align_up(Pz * 16);     // HitRec per Gaussian (written for the emitting ones only)
     L.total = o;
     return L;
 }
@@ -236,7 +249,7 @@ __device__ __forceinline__ float act_quat_inv_norm(float r, float x, float y, fl
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                       uint8_t* clamped, uint32_t* tiles_touched, uint4* hitrec, uint32_t* depth_key,
                        GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, bool sparse_view_hint, hipStream_t s);
 // zeroes the per-call part of the header and the chunk sums that k_preprocess adds into (chunk_sums == nullptr there: none)
 void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s);
@@ -261,14 +274,14 @@ struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtua
 // count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1
 // (LDS attribute) or -2 (sub-tile + depth + slot bits exceed 64).
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
-                        const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
+                        const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
                         long long bin_bound_hint, TileBinTimes* t, hipStream_t s);
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per

@@ -150,7 +150,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
              const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
              const float* __restrict__ colors_precomp, int prefiltered,
              int* __restrict__ radii, GaussRec* __restrict__ rec, uint8_t* __restrict__ clamped,
-             uint32_t* __restrict__ tiles_touched,
+             uint32_t* __restrict__ tiles_touched, uint4* __restrict__ hitrec,
              uint32_t* __restrict__ depth_key, GeomHeader* hdr, uint32_t binning_capacity,
              uint32_t* __restrict__ chunk_sums)
 {
@@ -296,17 +296,21 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         area_ref = area;
         key_out = __float_as_uint(vz);                         // vz > 0.2: bit order == float order
         // exact tile culling (common.h): count the tiles of the rectangle that can actually matter
+        // ... and leave the outcome per tile for the binning (common.h HitRec)
+        unsigned long long mask = 0ull;
         if (area > CULL_MAX_TILES) {
             tiles_out = area;
         } else {
             const float qmax = g.qmax;
             const float r_c = -con_b / con_c, r_a = -con_b / con_a;
-            uint32_t cnt = 0;
+            uint32_t cnt = 0, j = 0;
             for (int ty = miny; ty < maxy; ty++)
-                for (int tx = minx; tx < maxx; tx++)
-                    cnt += tile_hit(pix, piy, con_a, con_b, con_c, r_c, r_a, qmax, tx, ty) ? 1u : 0u;
+                for (int tx = minx; tx < maxx; tx++, j++)
+                    if (tile_hit(pix, piy, con_a, con_b, con_c, r_c, r_a, qmax, tx, ty)) { cnt++; mask |= 1ull << (j & 63u); }
             tiles_out = cnt;
         }
+        if (tiles_out != 0)
+            hitrec[idx] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), hit_geo(minx, miny, maxx - minx, area), key_out);
     } while (false);
 
     // this wave's share of the compaction's chunk sums (tilebin.hip k_compact_write): emitting Gaussians, instances,
@@ -473,16 +477,16 @@ __device__ __forceinline__ void colour_and_record(const ViewParams& vp, int idx,
     dst[2] = make_float4(rgb.z, pj.vz, qmax, 0.f);
 }
 
-// 6 waves per SIMD (80 VGPRs, no scratch); the split SH loader of raw mode needs 126 registers
+// 5 workgroups per CU (29.7 KB of LDS each; 80 VGPRs, no scratch); the split SH loader of raw mode needs 126 registers
 template <bool RAW>
-__global__ void __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(RAW ? 4 : 6, 8)))
+__global__ void __launch_bounds__(PL_THREADS) __attribute__((amdgpu_waves_per_eu(RAW ? 4 : 5, 8)))
 k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
                   const float* __restrict__ rotations, const float* __restrict__ opacities,
                   const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
                   const float* __restrict__ colors_precomp, int prefiltered,
                   int* __restrict__ radii, GaussRec* __restrict__ rec, uint8_t* __restrict__ clamped,
-                  uint32_t* __restrict__ tiles_touched, GeomHeader* hdr, uint32_t binning_capacity,
-                  uint32_t* __restrict__ chunk_sums)
+                  uint32_t* __restrict__ tiles_touched, uint4* __restrict__ hitrec, GeomHeader* hdr,
+                  uint32_t binning_capacity, uint32_t* __restrict__ chunk_sums)
 {
     __shared__ uint16_t s_near[PL_POOL];                     // pool-local ids of the near-plane passers, index order
     __shared__ int s_radius[PL_POOL];                        // results of the whole pool (0 for everything culled)
@@ -491,6 +495,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
     __shared__ uint32_t s_mid_id[PL_POOL];                   // ... and their pool-local ids
     __shared__ uint32_t s_tests[PL_POOL];                    // tile tests per survivor -> inclusive prefix
     __shared__ uint2 s_rect[PL_POOL];                        // tile rectangle of a survivor: min x | min y << 16, width
+    __shared__ uint32_t s_mask[PL_POOL][2];                  // outcome of its tile tests (common.h HitRec), rectangles <= 64 tiles
     __shared__ uint32_t s_wcnt[PL_ROUNDS * PL_WAVES];
     __shared__ uint32_t s_nmid;
     __shared__ uint32_t s_sum[3];
@@ -568,6 +573,10 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             my_ref += area;
             // rectangles of more than CULL_MAX_TILES tiles are emitted unculled (common.h): nothing to test
             if (area > CULL_MAX_TILES) s_tiles[loc] = area; else tests = area;
+            // the binning's record: origin, width and depth bits now, the mask after the tests (two 8-byte halves)
+            reinterpret_cast<uint2*>(hitrec + (base + (int)loc))[1] =
+                make_uint2(hit_geo(minx, miny, width, area), __float_as_uint(pj.vz));
+            s_mask[i][0] = 0u; s_mask[i][1] = 0u;
             s_mid[5][i] = qmax;                                   // vz is in the record now; the slot carries the threshold
             s_rect[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)width);   // gx, gy <= 65535 (launcher)
         }
@@ -602,11 +611,15 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             const int ty = (int)(rc.x >> 16) + (int)(j / rc.y), tx = (int)(rc.x & 0xffffu) + (int)(j % rc.y);
             const float con_a = s_mid[2][lo], con_b = s_mid[3][lo], con_c = s_mid[4][lo];
             const float r_c = -con_b / con_c, r_a = -con_b / con_a;
-            if (tile_hit(s_mid[0][lo], s_mid[1][lo], con_a, con_b, con_c, r_c, r_a, s_mid[5][lo], tx, ty))
+            if (tile_hit(s_mid[0][lo], s_mid[1][lo], con_a, con_b, con_c, r_c, r_a, s_mid[5][lo], tx, ty)) {
                 atomicAdd(&s_tiles[s_mid_id[lo]], 1u);           // still zero for these (phase 1)
+                atomicOr(&s_mask[lo][(j >> 5) & 1u], 1u << (j & 31u));   // (bits of 65..96-tile rectangles alias: mask unused)
+            }
         }
     }
     __syncthreads();
+    for (uint32_t i = (uint32_t)tid; i < n_mid; i += PL_THREADS)
+        reinterpret_cast<uint2*>(hitrec + (base + (int)s_mid_id[i]))[0] = make_uint2(s_mask[i][0], s_mask[i][1]);
     uint32_t my_cnt = 0, my_inst = 0;
 #pragma unroll
     for (int r = 0; r < PL_ROUNDS; r++) {
@@ -662,7 +675,7 @@ k_mark_visible(int P, const float* __restrict__ means3D, const float* __restrict
 void launch_preprocess(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                        const float* opacities, const float* shs, const float* cov3D_precomp,
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
-                       uint8_t* clamped, uint32_t* tiles_touched, uint32_t* depth_key,
+                       uint8_t* clamped, uint32_t* tiles_touched, uint4* hitrec, uint32_t* depth_key,
                        GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, bool sparse_view_hint, hipStream_t s)
 {
     static_assert(SCAN_TILE % PP_THREADS == 0, "a preprocess workgroup must lie inside one compaction chunk");
@@ -677,23 +690,23 @@ void launch_preprocess(const ViewParams& vp, const float* means3D, const float* 
         dim3 grid((vp.P + PL_POOL - 1) / PL_POOL), block(PL_THREADS);
         if (vp.raw)
             hipLaunchKernelGGL(k_preprocess_pool<true>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
-                               cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched, hdr,
-                               binning_capacity, chunk_sums);
+                               cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched, hitrec,
+                               hdr, binning_capacity, chunk_sums);
         else
             hipLaunchKernelGGL(k_preprocess_pool<false>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
-                               cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched, hdr,
-                               binning_capacity, chunk_sums);
+                               cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched, hitrec,
+                               hdr, binning_capacity, chunk_sums);
         return;
     }
     dim3 grid((vp.P + PP_THREADS - 1) / PP_THREADS), block(PP_THREADS);
     if (vp.raw)
         hipLaunchKernelGGL(k_preprocess<true>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                            cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                           depth_key, hdr, binning_capacity, chunk_sums);
+                           hitrec, depth_key, hdr, binning_capacity, chunk_sums);
     else
         hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                            cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
-                           depth_key, hdr, binning_capacity, chunk_sums);
+                           hitrec, depth_key, hdr, binning_capacity, chunk_sums);
 }
 
 void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s)

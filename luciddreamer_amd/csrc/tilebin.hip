@@ -159,52 +159,76 @@ __device__ __forceinline__ void part_chunk(uint32_t V, int nb, int b, uint32_t& 
 __device__ __forceinline__ int bin_slot(int bin) { return bin + (bin >> 4); }
 
 template <class F>
-__device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, int gy, const uint32_t* __restrict__ vis_list,
-                                           const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
-                                           const GaussRec* __restrict__ rec, const int* __restrict__ radii, F f)
+__device__ __forceinline__ void walk_chunk(uint32_t beg, uint32_t end, int gx, int gy, int own_max,
+                                           const uint32_t* __restrict__ vis_list, const uint32_t* __restrict__ offsets,
+                                           const uint4* __restrict__ hitrec, const GaussRec* __restrict__ rec,
+                                           const int* __restrict__ radii, F f)
 {
-    constexpr uint32_t SMALL = 20;
+    // Masked entries (common.h HitRec: rectangles of up to 64 tiles, the bulk): the set bits ARE the instances, in slot
+    // order.  Up to own_max of them are walked by their own lane, more by the whole wave (one round: lane j takes bit j).
+    // Unmasked entries (larger rectangles) are walked by the whole wave from the record, testing the culled ones again.
     const int lane = threadIdx.x & 63;
     const uint64_t lt = lanemask_lt();
     for (uint32_t k0 = beg; k0 < end; k0 += PART_THREADS) {          // beg, end are multiples of 64 or the list end
         const uint32_t k = k0 + threadIdx.x;
-        uint32_t idx = 0, tt = 0, off = 0, area = 0, dbits = 0;
-        int minx = 0, miny = 0, maxx = 0, maxy = 0;
-        float mx = 0.f, my = 0.f, ca = 0.f, cb = 0.f, cc = 0.f, qmax = 0.f, r_c = 0.f, r_a = 0.f;
+        uint32_t idx = 0, off = 0, geo = 0, dbits = 0, n_own = 0;
+        uint64_t mask = 0ull;
+        bool valid = false;
         if (k < end) {
             idx = vis_list[k];
-            tt = tiles_touched[idx];                 // > 0 for every entry of vis_list
             off = offsets[k];
-            const float4* g = reinterpret_cast<const float4*>(rec + idx);
-            const float4 q0 = g[0];
-            const float4 q1 = g[1];
-            const float4 q2 = g[2];
-            mx = q0.x; my = q0.y; ca = q0.z; cb = q0.w; cc = q1.x;
-            dbits = __float_as_uint(q2.y);           // view depth > 0.2: bit 31 clear, bit order == float order
-            qmax = q2.z;
-            r_c = -cb / cc; r_a = -cb / ca;
-            tile_rect_dev(mx, my, radii[idx], gx, gy, minx, miny, maxx, maxy);
-            area = (uint32_t)(maxx - minx) * (uint32_t)(maxy - miny);
+            const uint4 h = hitrec[idx];
+            mask = (uint64_t)h.x | ((uint64_t)h.y << 32);
+            geo = h.z; dbits = h.w;                                   // view depth > 0.2: bit 31 clear, bit order == float order
+            valid = true;
         }
-        const int rw = maxx - minx;
-        const bool culled = area <= CULL_MAX_TILES;   // same rule as the count in k_preprocess
-        if (tt != 0 && area <= SMALL) {
+        const bool masked = valid && geo != 0u;
+        const int minx = (int)(geo & 0xfffu), miny = (int)((geo >> 12) & 0xfffu);
+        const uint32_t rw = geo >> 24;
+        const uint32_t rcp = masked ? 65536u / rw + 1u : 0u;          // (j * rcp) >> 16 == j / rw for j < 64, rw <= 64
+        if (masked) n_own = (uint32_t)__popcll(mask);
+        if (masked && n_own <= (uint32_t)own_max) {
+            uint64_t m = mask;
             uint32_t o = off;
-            for (int y = miny; y < maxy; y++)
-                for (int x = minx; x < maxx; x++)
-                    if (tile_hit(mx, my, ca, cb, cc, r_c, r_a, qmax, x, y)) { f((uint32_t)(y * gx + x), o, idx, dbits); o++; }
+            while (m) {
+                const uint32_t j = (uint32_t)__ffsll((long long)m) - 1u;
+                m &= m - 1ull;
+                const uint32_t ry = (j * rcp) >> 16, rx = j - ry * rw;
+                f((uint32_t)((miny + (int)ry) * gx + minx + (int)rx), o, idx, dbits);
+                o++;
+            }
         }
-        uint64_t big = __ballot(tt != 0 && area > SMALL);
+        uint64_t coop = __ballot(masked && n_own > (uint32_t)own_max);
+        while (coop) {
+            const int src = __ffsll((long long)coop) - 1;
+            coop &= coop - 1;
+            const uint32_t b_lo = __shfl((uint32_t)mask, src), b_hi = __shfl((uint32_t)(mask >> 32), src);
+            const uint64_t b_mask = (uint64_t)b_lo | ((uint64_t)b_hi << 32);
+            const uint32_t b_geo = __shfl(geo, src), b_rcp = __shfl(rcp, src);
+            const uint32_t b_idx = __shfl(idx, src), b_db = __shfl(dbits, src), b_off = __shfl(off, src);
+            if ((b_mask >> lane) & 1ull) {
+                const uint32_t b_rw = b_geo >> 24;
+                const uint32_t ry = ((uint32_t)lane * b_rcp) >> 16, rx = (uint32_t)lane - ry * b_rw;
+                f((uint32_t)(((int)((b_geo >> 12) & 0xfffu) + (int)ry) * gx + (int)(b_geo & 0xfffu) + (int)rx),
+                  b_off + (uint32_t)__popcll(b_mask & lt), b_idx, b_db);
+            }
+        }
+        uint64_t big = __ballot(valid && geo == 0u);
         while (big) {
             const int src = __ffsll((long long)big) - 1;
             big &= big - 1;
-            const uint32_t b_idx = __shfl(idx, src), b_area = __shfl(area, src), b_db = __shfl(dbits, src);
+            const uint32_t b_idx = __shfl(idx, src), b_db = __shfl(dbits, src);
             uint32_t b_off = __shfl(off, src);
-            const int b_minx = __shfl(minx, src), b_miny = __shfl(miny, src), b_rw = __shfl(rw, src);
-            const bool b_culled = __shfl((int)culled, src) != 0;
-            const float b_mx = __shfl(mx, src), b_my = __shfl(my, src), b_ca = __shfl(ca, src), b_cb = __shfl(cb, src);
-            const float b_cc = __shfl(cc, src), b_qmax = __shfl(qmax, src);
-            const float b_rc = __shfl(r_c, src), b_ra = __shfl(r_a, src);
+            // wave-uniform loads of the one record
+            const float4* g = reinterpret_cast<const float4*>(rec + b_idx);
+            const float4 q0 = g[0], q1 = g[1], q2 = g[2];
+            const float b_mx = q0.x, b_my = q0.y, b_ca = q0.z, b_cb = q0.w, b_cc = q1.x, b_qmax = q2.z;
+            const float b_rc = -b_cb / b_cc, b_ra = -b_cb / b_ca;
+            int b_minx, b_miny, b_maxx, b_maxy;
+            tile_rect_dev(b_mx, b_my, radii[b_idx], gx, gy, b_minx, b_miny, b_maxx, b_maxy);
+            const int b_rw = b_maxx - b_minx;
+            const uint32_t b_area = (uint32_t)b_rw * (uint32_t)(b_maxy - b_miny);
+            const bool b_culled = b_area <= CULL_MAX_TILES;           // same rule as the count in k_preprocess
             for (uint32_t j0 = 0; j0 < b_area; j0 += 64) {
                 const uint32_t j = j0 + lane;
                 bool hit = j < b_area;
@@ -310,9 +334,8 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
 // MODE 1: scatter (64-bit words into their bins)
 template <int MODE>
 __global__ void __launch_bounds__(PART_THREADS)
-k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* __restrict__ vis_list,
-       const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ tiles_touched,
-       const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
+k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, const uint32_t* __restrict__ vis_list,
+       const uint32_t* __restrict__ offsets, const uint4* __restrict__ hitrec, const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
        uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
        uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ inst_gid,
        unsigned long long* __restrict__ words)
@@ -337,14 +360,14 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, const uint32_t* _
     part_chunk(V, nb, b, beg, end);
     const uint32_t sub_mask = (1u << sub_shift) - 1u;
     if (MODE == 0) {
-        walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
+        walk_chunk(beg, end, gx, gy, own_max, vis_list, offsets, hitrec, rec, radii,
                    [&](uint32_t tile, uint32_t slot, uint32_t gid, uint32_t) {
                        if (slot < cap) { atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u); inst_gid[slot] = gid; }
                    });
         __syncthreads();
         for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[bin_slot(i)];
     } else {
-        walk_chunk(beg, end, gx, gy, vis_list, offsets, tiles_touched, rec, radii,
+        walk_chunk(beg, end, gx, gy, own_max, vis_list, offsets, hitrec, rec, radii,
                    [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
                        if (slot < cap) {
                            const uint32_t pos = atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u);
@@ -631,7 +654,7 @@ void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sum
 }
 
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
-                        const uint32_t* tiles_touched, const GaussRec* rec, const int* radii, GeomHeader* hdr,
+                        const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
                         long long bin_bound_hint, TileBinTimes* t, hipStream_t s)
@@ -664,16 +687,18 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (nb < 1) nb = 1;
     if (nb > PART_BLOCKS_MAX) nb = PART_BLOCKS_MAX;
     const size_t lds = ((size_t)pp.bins + pp.bins / 16 + 1) * 4;
+    // instances of one Gaussian walked by its own lane before the wave shares them (lr_tune_set("walk_own", n))
+    const int own_max = tune_get(TUNE_WALK_OWN) >= 0 ? tune_get(TUNE_WALK_OWN) : 12;
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
-                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
+                       own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words);
     if (t) t->mark(1, s);
     hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
                        part_hist, bin_total);
     if (t) t->mark(2, s);
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
-                       vis_list, offsets, tiles_touched, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
+                       own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words);
     if (t) t->mark(3, s);
     const int groups4 = (pp.bins + 3) / 4;
