@@ -140,16 +140,18 @@ inline ImgLayout img_layout(int W, int H) {
     L.total = o;
     return L;
 }
-struct BinLayout { size_t point_list, words, inst_gid, inst_grad, total; };
+struct BinLayout { size_t point_list, words, quad_hits, inst_gid, inst_grad, total; };
 __host__ __device__ inline BinLayout bin_layout(long long R) {
     // point_list sits at offset 0: the tile-sorted list of EMISSION slots e; inst_gid[e] is the Gaussian and
     // inst_grad[e] the slot the blend backward writes that instance's nine partial sums to (one plain 48-byte
     // store per tile instance instead of nine global atomics).  `words` holds the 64-bit [sub-tile | depth | slot]
-    // sort words between the scatter and the per-bin sort.  The backward resolves the R-dependent offsets on the
-    // device from GeomHeader::bin_bound.
+    // sort words between the scatter and the per-bin sort; once the list is sorted the same bytes hold `quad_hits`:
+    // four bytes per LIST POSITION, byte q = "this instance can reach alpha >= 1/255 somewhere in 8x8 quadrant q of its
+    // tile" (q = x half + 2 * y half), written by the blend forward's cull and read back by the blend backward, which
+    // used to repeat the test.  The backward resolves the R-dependent offsets on the device from GeomHeader::bin_bound.
     BinLayout L; size_t o = 0; size_t Rz = R > 0 ? (size_t)R : 1;
     L.point_list = o; o += align_up(Rz * 4);
-    L.words = o;      o += align_up(Rz * 8);
+    L.words = o;      L.quad_hits = o; o += align_up(Rz * 8);
     L.inst_gid = o;   o += align_up(Rz * 4);
     L.inst_grad = o;  o += align_up(Rz * sizeof(GradRec));
     L.total = o;
@@ -309,7 +311,7 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
 }
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
-                       uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s);
+                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits, hipStream_t s);
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,

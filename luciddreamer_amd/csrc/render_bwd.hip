@@ -5,9 +5,9 @@
 // recursion through accum_rec, background term, 0.99 clamp not differentiated, depth gradient
 // ignored).  The kernel is VALU-issue bound; the design removes wave-instructions:
 //
-//   * same two-level loop as the forward: per 64 staged Gaussians one lane each runs the exact
-//     quadrant test (box_hit) -> 64-bit candidate mask; only candidates (walked back to front with
-//     s_flbit) are evaluated per pixel.  Positions at or behind the deepest stop position of the wave's pixels
+//   * same two-level loop as the forward: per 64 staged Gaussians one lane each looks up the outcome of the forward's
+//     exact quadrant test (box_hit, kept per list position in the binning buffer) -> 64-bit candidate mask; only
+//     candidates (walked back to front with s_flbit) are evaluated per pixel.  Positions at or behind the deepest stop position of the wave's pixels
 //     (render_fwd.hip PixState::last) are masked out up front (backward.cu:500-502, made wave-uniform).
 //   * the nine per-(pixel,Gaussian) gradient terms reach memory as
 //       reference: 9 global float atomicAdd per contributing pixel x Gaussian pair (:537-583)
@@ -185,10 +185,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 {
     constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
-    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c, opacity, qmax (cull threshold), -   (Cp, opacity: one ds_read_b64; Cp, qmax x log2 e)
+    __shared__ float2 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
-    __shared__ float2 s_q3[BATCH];      // -b/c, -b/a
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
+    __shared__ uint32_t s_hit[BATCH];   // the forward's quadrant tests of each staged element (common.h BinLayout::quad_hits)
     // per-batch gradient accumulator, columns below.  Every wave owns a copy: a wave meets a staged candidate at most once
     // per batch, so its contribution is a plain store (nothing is ever added twice to one word), and the flush sums the
     // copies in a fixed order: the backward is bit-repeatable at every image size.  (!MERGE, 2-wave shape: both waves add
@@ -221,6 +221,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     const BinLayout BL = bin_layout((long long)hdr->bin_bound);
     const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
+    const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
 
     BwdPix PA, PB;
     PA.pxf = (float)pxA; PB.pxf = (float)pxB;
@@ -269,13 +270,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
         __syncthreads();                                  // previous batch fully consumed / flushed
         if (tid < cnt) {
             const uint32_t e = point_list[range.x + (pos_hi - tid)];     // emission index of this instance
+            s_hit[tid] = quad_hits[range.x + (pos_hi - tid)];
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[tid] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);        // as render_fwd.hip
-            s_q1[tid] = make_float4((-0.5f * LOG2E) * b.x, b.y, LOG2E * c.z, 0.f);
+            s_q1[tid] = make_float2((-0.5f * LOG2E) * b.x, b.y);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
-            s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
             s_id[tid] = e;
         }
         if (tid < BATCH) {
@@ -287,19 +288,18 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
         __syncthreads();
 
         for (int sb = 0; sb < cnt; sb += 64) {
-            // CULL: lane l tests staged Gaussian sb+l (list position pos_hi-(sb+l)) against the two 8x8 quadrants of the
-            // wave's box, each with its own deepest last contributor
+            // CULL: lane l takes staged Gaussian sb+l (list position pos_hi-(sb+l)): the forward's quadrant tests (byte q of
+            // the word: quadrant q = x half + 2 * y half, as the forward's wave q saw it; measured against repeating box_hit
+            // here: profiles/r03t_ab_bwd_cull.json), each quadrant with its own deepest last contributor.  Positions at or
+            // behind a quadrant's last contributor may never have been tested by the forward: excluded by pos < last
             bool hitL = false, hitR = false;
             {
                 const int j = sb + l;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 if (j < cnt && pos < wave_last) {
-                    const float4 a = s_q0[j];
-                    const float4 b = s_q1[j];
-                    const float2 r = s_q3[j];
-                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // conic x log2 e, like qmax
-                    hitL = pos < lastL && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0, bx0 + 7.0f, by0, by1);
-                    if (!QUAD) hitR = pos < lastR && box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.z, bx0 + 8.0f, bx1, by0, by1);
+                    const uint32_t h = s_hit[j] >> (QUAD ? 8 * w : 16 * w);
+                    hitL = pos < lastL && (h & 0xffu) != 0u;
+                    if (!QUAD) hitR = pos < lastR && (h & 0xff00u) != 0u;
                 }
             }
             const uint64_t maskL = __ballot(hitL), maskR = QUAD ? 0ull : __ballot(hitR);
@@ -310,7 +310,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const int j = sb + k;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 const float4 a = s_q0[j];
-                const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);      // Cp, opacity
+                const float2 b = s_q1[j];                         // Cp, opacity
                 const float4 c = s_q2[j];
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
@@ -354,7 +354,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 for (int a = 1; a < NACC; a++) v += s_acc[tid][a][k];      // fixed order over the waves
                 a9[k] = v;
             }
-            const float4 q0 = s_q0[tid], q1 = s_q1[tid];
+            const float4 q0 = s_q0[tid]; const float2 q1 = s_q1[tid];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;   // conic back from the scaled staging
             const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;

@@ -19,7 +19,8 @@
 //     __ballot turns the result into a 64-bit candidate mask.  BLEND: the wave walks only the set bits
 //     (s_ff1), in list order, all lanes evaluating the same Gaussian from broadcast ds_reads.  A
 //     non-candidate cannot reach alpha >= 1/255 on any pixel of the box (margin in common.h), so skipping
-//     it is exactly the reference's `continue` (forward.cu:338-339);
+//     it is exactly the reference's `continue` (forward.cu:338-339).  The outcome per list position and quadrant is left in
+//     the binning buffer for the backward, which used to repeat the test;
 //   * per-wave early termination via 64-bit __ballot (the reference only stops per block);
 //   * tiles are assigned to workgroups so that each XCD (its own 4 MiB L2) renders a contiguous
 //     band of the image and re-uses the GaussRecs of Gaussians that straddle neighbouring tiles.
@@ -72,7 +73,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
              const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             float* __restrict__ out_color, float* __restrict__ out_depth)
+             float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
     __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity, depth, qmax (cull threshold, x log2 e)
@@ -126,6 +127,9 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                     const float2 r = s_q3[j];
                     const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // conic x log2 e, like qmax
                     hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.w, bx0, bx1, by0, by1);
+                    // the outcome is kept for the backward (common.h BinLayout::quad_hits): every position a pixel of this
+                    // quadrant can have blended lies in a chunk this wave culled
+                    quad_hits[4 * ((size_t)range.x + (size_t)(base + j)) + w] = hit ? 1 : 0;
                 }
             }
             uint64_t mask = __ballot(hit);
@@ -163,14 +167,14 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
-                       uint32_t* n_contrib, float* out_color, float* out_depth, hipStream_t s)
+                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
     hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid,
-                       rec, bg, final_T, n_contrib, out_color, out_depth);
+                       rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
 }
 
 }  // namespace lr
