@@ -88,6 +88,10 @@ def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, featur
 
 mark_visible = _C_ext.mark_visible
 check = _C_ext.check
+# the operator with its autograd node compiled (csrc/torch_ext.cpp RasterizeFn); returns (color, radii, depth, geom), the
+# call's num_rendered is read with last_num_rendered()
+rasterize_autograd = _C_ext.rasterize_autograd
+last_num_rendered = _C_ext.last_num_rendered
 
 
 def request_early_header():

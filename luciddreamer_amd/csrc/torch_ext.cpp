@@ -281,6 +281,117 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
     return result;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The autograd node of the drop-in operator in C++ (RAST/depth_diff_gaussian_rasterization_min/__init__.py:44-156 is a
+// Python torch.autograd.Function).  With the Python node a 1080p view cost ~230 us of host time against ~190 us of GPU
+// time (profiles/r03v_host_profile.txt): the drop-in path was host-bound.  Here forward and backward run without the
+// interpreter: the engine's device thread calls lr_backward directly, no GIL, no argument tuples.  luciddreamer_amd/
+// rasterizer.py keeps the Python node for settings.debug (it writes the reference's snapshot_*.dump files on failure).
+//
+// forward arguments: the eight differentiable inputs in the reference's order (means3D, means2D, sh, colors_precomp,
+// opacities, scales, rotations, cov3Ds_precomp; absent ones as empty tensors), the four tensors of the settings tuple,
+// then its scalars, the async-mode binning capacity and the fused-accumulation switch (config.py).
+// returns (color, radii, depth, geom); num_rendered of the call is left in a thread-local (last_num_rendered()).
+// ------------------------------------------------------------------------------------------------------------------
+thread_local int64_t g_last_num_rendered = 0;
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
+    static constexpr int kForwardArgs = 21;
+
+    static variable_list forward(AutogradContext* ctx, const at::Tensor& means3D, const at::Tensor& means2D, const at::Tensor& sh,
+                                 const at::Tensor& colors, const at::Tensor& opacities, const at::Tensor& scales,
+                                 const at::Tensor& rotations, const at::Tensor& cov3D, const at::Tensor& bg,
+                                 const at::Tensor& viewmatrix, const at::Tensor& projmatrix, const at::Tensor& campos,
+                                 double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W, int64_t degree,
+                                 bool prefiltered, int64_t binning_capacity, bool fused_accumulate)
+    {
+        FwdResult r = rasterize_gaussians(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix,
+                                          projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, false,
+                                          binning_capacity);
+        g_last_num_rendered = std::get<0>(r);
+        const at::Tensor &color = std::get<1>(r), &depth = std::get<2>(r), &radii = std::get<3>(r), &geom = std::get<4>(r);
+        // the inputs the reference saves go through save_for_backward (__init__.py:93: an in-place change of one of them before
+        // backward is an error there too); everything else is kept as plain data, without a version check
+        ctx->save_for_backward({means3D, sh, colors, scales, rotations, cov3D});
+        ctx->saved_data["means2D"] = means2D;
+        ctx->saved_data["opacities"] = opacities;
+        ctx->saved_data["bg"] = bg;
+        ctx->saved_data["viewmatrix"] = viewmatrix;
+        ctx->saved_data["projmatrix"] = projmatrix;
+        ctx->saved_data["campos"] = campos;
+        ctx->saved_data["radii"] = radii;
+        ctx->saved_data["geom"] = geom;
+        ctx->saved_data["binning"] = std::get<5>(r);
+        ctx->saved_data["img"] = std::get<6>(r);
+        ctx->saved_data["scale_modifier"] = scale_modifier;
+        ctx->saved_data["tan_fovx"] = tan_fovx;
+        ctx->saved_data["tan_fovy"] = tan_fovy;
+        ctx->saved_data["H"] = H;
+        ctx->saved_data["W"] = W;
+        ctx->saved_data["degree"] = degree;
+        ctx->saved_data["num_rendered"] = std::get<0>(r);
+        ctx->saved_data["capacity"] = binning_capacity;
+        ctx->saved_data["fused"] = fused_accumulate;
+        ctx->mark_non_differentiable({radii, geom});
+        return {color, radii, depth, geom};
+    }
+
+    static variable_list backward(AutogradContext* ctx, variable_list grad_out)
+    {
+        const variable_list in = ctx->get_saved_variables();
+        const at::Tensor &means3D = in[0], &sh = in[1], &colors = in[2], &scales = in[3], &rotations = in[4], &cov3D = in[5];
+        auto& d = ctx->saved_data;
+        const at::Tensor means2D = d["means2D"].toTensor(), opacities = d["opacities"].toTensor(), bg = d["bg"].toTensor(),
+                         viewmatrix = d["viewmatrix"].toTensor(), projmatrix = d["projmatrix"].toTensor(),
+                         campos = d["campos"].toTensor();
+        const int64_t H = d["H"].toInt(), W = d["W"].toInt();
+        const c10::Device dev = means3D.device();
+        at::Tensor g_color = grad_out[0];
+        if (!g_color.defined()) g_color = at::zeros({3, H, W}, at::TensorOptions().dtype(at::kFloat).device(dev));
+        const OptT g_depth = grad_out[2].defined() ? OptT(grad_out[2]) : OptT();
+        // config.set_fused_grad_accumulation: a leaf input whose .grad exists (contiguous float32, 16-byte aligned: the kernels
+        // accumulate with 16-byte accesses) receives `+=` inside the kernel; its slot of the result stays undefined
+        const bool fused = d["fused"].toBool();
+        auto leaf_grad = [&](const at::Tensor& t) -> OptT {
+            if (!fused || !t.defined() || t.numel() == 0 || !t.requires_grad() || !t.is_leaf()) return OptT();
+            const at::Tensor& g = t.grad();
+            if (!g.defined() || !g.is_contiguous() || g.scalar_type() != at::kFloat || g.device() != dev ||
+                reinterpret_cast<uintptr_t>(g.data_ptr()) % 16 != 0)
+                return OptT();
+            return OptT(g);
+        };
+        // order of rasterize_gaussians_backward's result: means2D, colors, opacity, means3D, cov3D, sh, scales, rotations
+        std::vector<OptT> acc;
+        if (fused)
+            acc = { leaf_grad(means2D), leaf_grad(colors), leaf_grad(opacities), leaf_grad(means3D), leaf_grad(cov3D), leaf_grad(sh),
+                    leaf_grad(scales), leaf_grad(rotations) };
+        const std::vector<OptT> g = rasterize_gaussians_backward(
+            bg, means3D, d["radii"].toTensor(), colors, scales, rotations, d["scale_modifier"].toDouble(), cov3D, viewmatrix,
+            projmatrix, d["tan_fovx"].toDouble(), d["tan_fovy"].toDouble(), g_color, g_depth, sh, d["degree"].toInt(), campos,
+            d["geom"].toTensor(), d["num_rendered"].toInt(), d["binning"].toTensor(), d["img"].toTensor(), false,
+            d["capacity"].toInt(), acc, true);
+        auto slot = [&](int k) { return g[k].has_value() ? *g[k] : at::Tensor(); };
+        variable_list out(kForwardArgs);                       // one per forward argument; undefined = no gradient
+        out[0] = slot(3); out[1] = slot(0); out[2] = slot(5); out[3] = slot(1); out[4] = slot(2); out[5] = slot(6); out[6] = slot(7);
+        out[7] = slot(4);
+        return out;
+    }
+};
+
+std::vector<at::Tensor> rasterize_autograd(const at::Tensor& means3D, const at::Tensor& means2D, const at::Tensor& sh,
+                                           const at::Tensor& colors, const at::Tensor& opacities, const at::Tensor& scales,
+                                           const at::Tensor& rotations, const at::Tensor& cov3D, const at::Tensor& bg,
+                                           const at::Tensor& viewmatrix, const at::Tensor& projmatrix, const at::Tensor& campos,
+                                           double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W,
+                                           int64_t degree, bool prefiltered, int64_t binning_capacity, bool fused_accumulate)
+{
+    return RasterizeFn::apply(means3D, means2D, sh, colors, opacities, scales, rotations, cov3D, bg, viewmatrix, projmatrix, campos,
+                              scale_modifier, tan_fovx, tan_fovy, H, W, degree, prefiltered, binning_capacity, fused_accumulate);
+}
+
 at::Tensor mark_visible(const at::Tensor& means3D, const at::Tensor& viewmatrix, const at::Tensor& projmatrix)
 {
     require_device(means3D, "means3D");
@@ -341,6 +452,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_gaussians_backward", &rasterize_gaussians_backward);
     m.def("rasterize_gaussians_raw", &rasterize_gaussians_raw);
     m.def("rasterize_gaussians_raw_backward", &rasterize_gaussians_raw_backward);
+    m.def("rasterize_autograd", &rasterize_autograd);
+    m.def("last_num_rendered", [] { return g_last_num_rendered; });
     m.def("mark_visible", &mark_visible);
     m.def("check", &check);
     m.def("header_post", &header_post);

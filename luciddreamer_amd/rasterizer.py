@@ -109,8 +109,31 @@ class _RasterizeGaussians(torch.autograd.Function):
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
-    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
-                                     cov3Ds_precomp, raster_settings)
+    """The operator.  Its autograd node is compiled (csrc/torch_ext.cpp RasterizeFn: forward and backward run without the
+    interpreter -- the Python node below cost more host time per 1080p view than the GPU needs for it); with settings.debug
+    the Python node runs instead, because it is the one that writes the reference's snapshot_fw.dump / snapshot_bw.dump."""
+    rs = raster_settings
+    if rs.debug:
+        return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, rs)
+    capacity = config.capacity_for(means3D, rs)
+    verifying = config.verifying(capacity)
+    fused = config.fused_grad_accumulation()
+
+    def run(cap):
+        return _C.rasterize_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
+                                     rs.viewmatrix, rs.projmatrix, rs.campos, rs.scale_modifier, rs.tanfovx, rs.tanfovy,
+                                     rs.image_height, rs.image_width, rs.sh_degree, rs.prefiltered, cap, fused)
+    if verifying:
+        _C.request_early_header()
+    color, radii, depth, geom = run(capacity)
+    # policy "verify" (config.py): the whole forward is enqueued; if the view needs more instances than its buffer holds it is
+    # rendered again in exact mode -- what is returned is always a complete image (the first node is simply dropped)
+    if verifying and config.verify(means3D, rs, _C.take_early_ticket()):
+        capacity = 0
+        color, radii, depth, geom = run(0)
+    config.note_forward(means3D, rs, _C.last_num_rendered(), geom, capacity)
+    return color, radii, depth
 
 
 class _RasterizeGaussiansRaw(torch.autograd.Function):

@@ -73,3 +73,69 @@ def test_backward_reductions_agree(hip_device, W, H):
     again = _run(cloud, cam, hip_device, g)
     for k in again["grads"]:
         assert np.array_equal(again["grads"][k], outs[1]["grads"][k]), k
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_compiled_and_python_autograd_nodes_agree(hip_device, fused):
+    """The operator's autograd node exists twice: compiled (csrc/torch_ext.cpp RasterizeFn, the default) and in Python
+    (rasterizer._RasterizeGaussians, used with settings.debug because it writes the reference's snapshot dumps).  Same C
+    calls underneath: images and gradients must be bit-identical, also with fused gradient accumulation into existing
+    .grad tensors and with an upstream gradient on the depth output."""
+    from luciddreamer_amd import config
+    cloud = synthetic.make_cloud(20_000, "band", 11)
+    cam = cameras.rotate360_path(400, 240, n_views=30)[4]
+    g, gd = synthetic.upstream_grad(240, 400), torch.rand(1, 240, 400)
+    config.set_fused_grad_accumulation(fused)
+    try:
+        a = hp.run_hip(cloud, cam, 3, torch.zeros(3), hip_device, g, debug=False, grad_depth=gd)
+        b = hp.run_hip(cloud, cam, 3, torch.zeros(3), hip_device, g, debug=True, grad_depth=gd)
+    finally:
+        config.set_fused_grad_accumulation(False)
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"]) and np.array_equal(a["radii"], b["radii"])
+    assert "RasterizeFn" in a["color_t"].grad_fn.name() and "RasterizeGaussians" in b["color_t"].grad_fn.name()
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    assert float(np.abs(a["grads"]["means3D"]).max()) > 0
+
+
+def test_compiled_node_accumulates_into_existing_grads_and_checks_versions(hip_device):
+    """Two views through the compiled node with fused accumulation: .grad ends up the sum of the two views' gradients (first
+    view: no .grad yet -> autograd installs the dense tensor; second: `+=` inside the kernel).  And an in-place change of a
+    saved input between forward and backward is an error, as with the reference's ctx.save_for_backward."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import config
+    dev = hip_device
+    cloud = synthetic.make_cloud(8_000, "band", 2)
+    cams = [c.to(dev) for c in cameras.rotate360_path(320, 200, n_views=30)[3:5]]
+    g = synthetic.upstream_grad(200, 320).to(dev)
+
+    def leafs():
+        return {k: v.detach().to(dev).requires_grad_(True) for k, v in cloud.items()}
+
+    def render(p, cam, m2d):
+        tfx, tfy = hp.tan_fov(cam)
+        rs = GaussianRasterizationSettings(cam.image_height, cam.image_width, tfx, tfy, torch.zeros(3, device=dev), 1.0,
+                                           cam.world_view_transform, cam.full_proj_transform, 3, cam.camera_center, False, False)
+        return GaussianRasterizer(rs)(means3D=p["means3D"], means2D=m2d, opacities=p["opacities"], shs=p["shs"],
+                                      scales=p["scales"], rotations=p["rotations"])[0]
+    sums = []
+    for fused in (False, True):
+        config.set_fused_grad_accumulation(fused)
+        try:
+            p = leafs()
+            for cam in cams:
+                m2d = torch.zeros_like(p["means3D"], requires_grad=True)
+                (render(p, cam, m2d) * g).sum().backward()
+        finally:
+            config.set_fused_grad_accumulation(False)
+        sums.append({k: v.grad.cpu().numpy() for k, v in p.items()})
+    for k in sums[0]:
+        scale = float(np.abs(sums[0][k]).max())
+        assert float(np.abs(sums[0][k] - sums[1][k]).max()) <= 2e-6 * scale, k       # same two addends per element
+    p = leafs()
+    m2d = torch.zeros_like(p["means3D"], requires_grad=True)
+    color = render(p, cams[0], m2d)
+    with torch.no_grad():
+        p["scales"].mul_(1.0)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        (color * g).sum().backward()
