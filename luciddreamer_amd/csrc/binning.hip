@@ -30,14 +30,14 @@ k_radix_hist(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ n_d
     const uint32_t n = *n_dev;
     const uint32_t b = blockIdx.x, nb = gridDim.x;
     s_hist[threadIdx.x] = 0;
-    __syncthreads();
+    lds_barrier();
     const uint64_t beg = (uint64_t)b * chunk;
     uint64_t end = beg + chunk; if (end > n) end = n;
     for (uint64_t i = beg + threadIdx.x; i < end; i += SORT_THREADS) {
         const uint32_t d = (keys[i] >> shift) & mask;
         atomicAdd(&s_hist[d], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     hist[(size_t)threadIdx.x * nb + b] = s_hist[threadIdx.x];
 }
 
@@ -65,7 +65,7 @@ k_radix_scan(uint32_t* __restrict__ hist, int nb, uint32_t* __restrict__ totals)
     }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) s_wave[w] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t wbase = 0;
     for (int i = 0; i < w; i++) wbase += s_wave[i];
     uint32_t run = wbase + inc - sum;
@@ -105,11 +105,11 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
             if (lane >= off) inc += u;
         }
         if (lane == 63) s_cnt[0][w] = inc;
-        __syncthreads();
+        lds_barrier();
         uint32_t wbase = 0;
         for (int i = 0; i < w; i++) wbase += s_cnt[0][i];
         s_run[tid] = wbase + inc - t + hist[(size_t)tid * nb + b];
-        __syncthreads();
+        lds_barrier();
     }
 
     const uint64_t lt = lanemask_lt();
@@ -117,7 +117,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
         // phase 1: load keys, per-wave digit histogram
 #pragma unroll
         for (int i = 0; i < 4; i++) s_cnt[i][tid] = 0;
-        __syncthreads();
+        lds_barrier();
         uint32_t key[SORT_ITEMS], val[SORT_ITEMS];
         const uint64_t wbeg = tile + (uint64_t)w * (WAVE * SORT_ITEMS);
 #pragma unroll
@@ -128,7 +128,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
             val[i] = ok ? (IOTA ? (uint32_t)g : vals_in[g]) : 0u;
             if (ok) atomicAdd(&s_cnt[w][(key[i] >> shift) & mask], 1u);
         }
-        __syncthreads();
+        lds_barrier();
         // phase 2: thread d turns the 4 wave counts of digit d into running bases
         {
             uint32_t run = s_run[tid];
@@ -136,7 +136,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
             for (int i = 0; i < 4; i++) { uint32_t c = s_cnt[i][tid]; s_cnt[i][tid] = run; run += c; }
             s_run[tid] = run;
         }
-        __syncthreads();
+        lds_barrier();
         // phase 3: wave-synchronous stable ranking + scatter
         volatile uint32_t* cnt = s_cnt[w];
 #pragma unroll
@@ -162,7 +162,7 @@ k_radix_scatter(const uint32_t* __restrict__ keys_in, const uint32_t* __restrict
             if (ok && (m & lt) == 0) cnt[d] += (uint32_t)__popcll(m);   // group leader advances the base
             __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
+        lds_barrier();
     }
 }
 

@@ -37,9 +37,11 @@ static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 //   x, y : mask bits 0-31, 32-63      z : minx | miny << 12 | rw << 24, or 0 = no mask (larger rectangle, or a tile grid
 //   w    : view depth as uint32                                               beyond 4096: the walk tests / emits from the record)
 constexpr uint32_t HIT_MASK_TILES = 64;
-__host__ __device__ inline uint32_t hit_geo(int minx, int miny, int rw, uint32_t area)
+constexpr int HIT_ORIGIN_LIMIT = 4096;       // rectangle origins the record can hold (12 bits each)
+__host__ __device__ inline uint32_t hit_geo(int minx, int miny, int rw, uint32_t area, int origin_limit)
 {
-    return (area <= HIT_MASK_TILES && minx < 4096 && miny < 4096) ? ((uint32_t)minx | ((uint32_t)miny << 12) | ((uint32_t)rw << 24)) : 0u;
+    return (area <= HIT_MASK_TILES && minx < origin_limit && miny < origin_limit)
+               ? ((uint32_t)minx | ((uint32_t)miny << 12) | ((uint32_t)rw << 24)) : 0u;
 }
 
 // Header at offset 0 of the geom buffer (device-resident view state).
@@ -58,6 +60,19 @@ struct GeomHeader {
     uint32_t reserved_tail[3];
 };
 static_assert(sizeof(GeomHeader) == 256, "GeomHeader must be 256 bytes");
+
+// Workgroup barrier with the wait for this wave's own LDS operations spelled out.  __syncthreads() implies it (workgroup-scope
+// release), but ROCm 7.2's hipcc dropped the `s_waitcnt lgkmcnt(0)` in front of the s_barrier that closes a batch of
+// k_render_bwd's two-wave shape (a divergent ds_write / ds_add_f32 at the end of the candidate loop, then the loop exit): the
+// other wave's flush could read the accumulator before the last store had landed.  Found as a timing-dependent gradient of
+// ONE Gaussian in ~5 % of the runs of the LDS-atomic reduction (whose ds_add_f32 takes ~3 cycles per lane: a wide window);
+// the default reduction's plain store never showed it in 2000 runs, but the instruction was missing there too.  Inline asm is
+// opaque to the waitcnt insertion, so this wait cannot be optimised away; every barrier of the library goes through here.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
 
 constexpr size_t ALIGN = 256;
 __host__ __device__ inline size_t align_up(size_t v) { return (v + ALIGN - 1) / ALIGN * ALIGN; }
@@ -229,6 +244,7 @@ struct ViewParams {
     const float* campos;    // device, 3 floats
     float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
     int W, H, gx, gy, P, D, M;
+    int hit_origin_limit;         // HIT_ORIGIN_LIMIT; 0 (lr_tune_set("hit_mask", 0), tests) = no masks: every rectangle walked from its record
     // raw-parameter mode (lr_forward_raw / lr_backward_raw): scales, rotations and opacities are the STORED
     // GaussianModel parameters (pre exp / normalize / sigmoid, R/scene/gaussian_model.py:97-117) and the SH
     // coefficients come as two arrays, `shs` = features_dc [P,1,3] and `sh_rest` = features_rest [P,M-1,3]
@@ -283,7 +299,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per

@@ -463,7 +463,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                         s_b[0][o + q] = b[q]; s_b[1][o + q] = bx[q]; s_b[2][o + q] = by[q]; s_b[3][o + q] = bz[q];
                     }
                 }
-                __syncthreads();
+                lds_barrier();
                 // four steps (16 Gaussians) at a time: all row loads are issued before the first store, which the
                 // compiler cannot do across steps by itself (the accumulate loads may alias the previous stores)
                 for (int it0 = 0; it0 < 8; it0 += 4) {
@@ -505,7 +505,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                         if (k == 0 && g < n_here) { s_ddir[0][g] = px; s_ddir[1][g] = py; s_ddir[2][g] = pz; }
                     }
                 }
-                __syncthreads();
+                lds_barrier();
             }
             if (live) dL_ddir = { s_ddir[0][lane], s_ddir[1][lane], s_ddir[2][lane] };
         }
@@ -513,7 +513,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             gauss_backward_one<RAW>(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
                                dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale,
                                dL_drot, accum_mask, acc16);
-        __syncthreads();                     // the LDS planes are rewritten by the next round
+        lds_barrier();                     // the LDS planes are rewritten by the next round
     }
 }
 

@@ -127,7 +127,7 @@ k_box_minmax(int P, const float* __restrict__ pts, const uint32_t* __restrict__ 
 #pragma unroll
         for (int c = 0; c < 3; c++) { s_mn[w][c] = mn[c]; s_mx[w][c] = mx[c]; }
     }
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x < 3) {
         const int c = threadIdx.x;
         float a = s_mn[0][c], b = s_mx[0][c];
@@ -182,10 +182,11 @@ k_box_knn(int P, const float4* __restrict__ sorted, const float* __restrict__ bo
         // point of this workgroup still needs it
         const float d = live ? dist_box(box, me.x, me.y, me.z) : FLT_MAX;
         const bool need = live && !(d > reject || d > best[2]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // as common.h lds_barrier()
         if (!__syncthreads_or(need)) continue;
         const int j = b * BOX + threadIdx.x;
         s_pts[threadIdx.x] = (j < P) ? sorted[j] : make_float4(FLT_MAX, FLT_MAX, FLT_MAX, 0);
-        __syncthreads();
+        lds_barrier();
         if (need) {
             const int cnt = min(BOX, P - b * BOX);
             for (int k = 0; k < cnt; k++) {
@@ -195,7 +196,7 @@ k_box_knn(int P, const float4* __restrict__ sorted, const float* __restrict__ bo
                 update3(dx * dx + dy * dy + dz * dz, best);
             }
         }
-        __syncthreads();
+        lds_barrier();
     }
     if (live) out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
 }

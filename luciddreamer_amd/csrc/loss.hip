@@ -56,9 +56,9 @@ __device__ __forceinline__ float block_sum(float v, float* s_tmp)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     const int w = threadIdx.x >> 6;
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) s_tmp[w] = v;
-    __syncthreads();
+    lds_barrier();
     return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
@@ -117,7 +117,7 @@ k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restr
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // horizontal pass: item = (row, group of 4 adjacent output columns); 336 items = up to two per thread, kept in
     // registers until every thread has read its inputs (the maps overwrite the halo regions)
@@ -143,7 +143,7 @@ k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restr
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < HROUNDS; r++) {
         const int it = tid + r * LTHREADS;
@@ -155,7 +155,7 @@ k_ssim_fwd(int H, int W, int tiles_x, int tiles_y, Win win, const float* __restr
                 for (int o = 0; o < 4; o++) s_h[m][row][c0 + o] = hs[r][m][o];
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // vertical pass: thread = (column, group of 4 adjacent output rows)
     const int col = tid % LT, r0 = (tid / LT) * 4;
@@ -211,10 +211,10 @@ __device__ __forceinline__ void loss_final(int n_blocks, double n_elems, float l
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n_blocks; i += LTHREADS) { const float2 p = partials[i]; a += p.x; b += p.y; }
     s_a[threadIdx.x] = a; s_b[threadIdx.x] = b;
-    __syncthreads();
+    lds_barrier();
     for (int off = LTHREADS / 2; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) { s_a[threadIdx.x] += s_a[threadIdx.x + off]; s_b[threadIdx.x] += s_b[threadIdx.x + off]; }
-        __syncthreads();
+        lds_barrier();
     }
     if (threadIdx.x == 0) {
         const float ssim = (float)(s_a[0] / n_elems), l1 = (float)(s_b[0] / n_elems);
@@ -244,7 +244,7 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
     if (out3 != nullptr && blockIdx.x == 0) {
         double* s_a = reinterpret_cast<double*>(s_raw);
         loss_final(n_blocks, n_elems, lambda, partials, out3, s_a, s_a + LTHREADS);
-        __syncthreads();
+        lds_barrier();
     }
     float (*s_d)[LR_IN][LR_IN + 1] = reinterpret_cast<float (*)[LR_IN][LR_IN + 1]>(s_raw);
     float (*s_h)[LR_IN][LT + 1] = reinterpret_cast<float (*)[LR_IN][LT + 1]>(s_raw);
@@ -290,7 +290,7 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
         for (int i = 0; i < NSTAGE; i++)
             if (li[i] >= 0) { (&s_d[0][0][0])[li[i]] = r1[i]; (&s_d[1][0][0])[li[i]] = r2[i]; (&s_d[2][0][0])[li[i]] = r3[i]; }
     }
-    __syncthreads();
+    lds_barrier();
     constexpr int HITEMS = LR_IN * (LT / 4), HROUNDS = (HITEMS + LTHREADS - 1) / LTHREADS;
     float hs[HROUNDS][3][4];
 #pragma unroll
@@ -313,7 +313,7 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < HROUNDS; r++) {
         const int it = tid + r * LTHREADS;
@@ -325,7 +325,7 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
                 for (int o = 0; o < 4; o++) s_h[m][row][c0 + o] = hs[r][m][o];
         }
     }
-    __syncthreads();
+    lds_barrier();
     float acc[3][4];
 #pragma unroll
     for (int m = 0; m < 3; m++) {

@@ -176,11 +176,11 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         const uint64_t m = __ballot(pass);
         const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
         if (l == 0) s_wcnt[w] = (uint32_t)__popcll(m);
-        __syncthreads();
+        lds_barrier();
         uint32_t before = 0;
         for (int i = 0; i < w; i++) before += s_wcnt[i];
         if (pass) s_list[before + __popcll(m & ((1ull << l) - 1ull))] = (uint32_t)gid;
-        __syncthreads();
+        lds_barrier();
     }
     uint32_t n_pass = 0;
 #pragma unroll
@@ -310,7 +310,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
             tiles_out = cnt;
         }
         if (tiles_out != 0)
-            hitrec[idx] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), hit_geo(minx, miny, maxx - minx, area), key_out);
+            hitrec[idx] = make_uint4((uint32_t)mask, (uint32_t)(mask >> 32), hit_geo(minx, miny, maxx - minx, area, vp.hit_origin_limit), key_out);
     } while (false);
 
     // this wave's share of the compaction's chunk sums (tilebin.hip k_compact_write): emitting Gaussians, instances,
@@ -520,7 +520,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
         m[r] = __ballot(pass[r]);
         if (l == 0) s_wcnt[r * PL_WAVES + w] = (uint32_t)__popcll(m[r]);
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t n_near = 0;
 #pragma unroll
     for (int r = 0; r < PL_ROUNDS; r++) {
@@ -529,7 +529,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
         for (int i = 0; i < PL_WAVES; i++) { if (i < w) before += s_wcnt[r * PL_WAVES + i]; n_near += s_wcnt[r * PL_WAVES + i]; }
         if (pass[r]) s_near[before + __popcll(m[r] & ((1ull << l) - 1ull))] = (uint16_t)(r * PL_THREADS + tid);
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 2: projection / covariance / rectangle on dense lanes; survivors are parked (in arrival order: nothing
     // observable depends on it -- every output is per Gaussian, the chunk sums are integer sums)
@@ -553,7 +553,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             s_mid_id[slot] = loc; s_radius[loc] = pj.radius;
         }
     }
-    __syncthreads();
+    lds_barrier();
 
     // ---- phase 3a: colour and record on dense lanes; every survivor leaves its rectangle for the count
     const uint32_t n_mid = s_nmid;
@@ -575,14 +575,14 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             if (area > CULL_MAX_TILES) s_tiles[loc] = area; else tests = area;
             // the binning's record: origin, width and depth bits now, the mask after the tests (two 8-byte halves)
             reinterpret_cast<uint2*>(hitrec + (base + (int)loc))[1] =
-                make_uint2(hit_geo(minx, miny, width, area), __float_as_uint(pj.vz));
+                make_uint2(hit_geo(minx, miny, width, area, vp.hit_origin_limit), __float_as_uint(pj.vz));
             s_mask[i][0] = 0u; s_mask[i][1] = 0u;
             s_mid[5][i] = qmax;                                   // vz is in the record now; the slot carries the threshold
             s_rect[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)width);   // gx, gy <= 65535 (launcher)
         }
         s_tests[i0 + tid] = tests;                                // entries between n_mid and the end of the round: zero
     }
-    __syncthreads();
+    lds_barrier();
     // ---- phase 3b: exact tile culling (common.h): the (Gaussian, tile) pairs of the whole pool laid end to end --
     // inclusive scan of the test counts, every thread finds the owner of its pair by bisection -- and counted with integer
     // LDS atomics (order-free)
@@ -595,12 +595,12 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (l >= off) inc += t; }
             if (l == 63) s_wcnt[w] = inc;
-            __syncthreads();
+            lds_barrier();
             uint32_t before = run;
 #pragma unroll
             for (int q = 0; q < PL_WAVES; q++) { if (q < w) before += s_wcnt[q]; run += s_wcnt[q]; }
             s_tests[i0 + tid] = before + inc;                     // inclusive prefix
-            __syncthreads();
+            lds_barrier();
         }
         const uint32_t total = run;
         for (uint32_t t = (uint32_t)tid; t < total; t += PL_THREADS) {
@@ -617,7 +617,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             }
         }
     }
-    __syncthreads();
+    lds_barrier();
     for (uint32_t i = (uint32_t)tid; i < n_mid; i += PL_THREADS)
         reinterpret_cast<uint2*>(hitrec + (base + (int)s_mid_id[i]))[0] = make_uint2(s_mask[i][0], s_mask[i][1]);
     uint32_t my_cnt = 0, my_inst = 0;
@@ -636,7 +636,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
         }
         if (l == 0 && (my_ref | my_inst) != 0) { atomicAdd(&s_sum[0], my_cnt); atomicAdd(&s_sum[1], my_inst); atomicAdd(&s_sum[2], my_ref); }
     }
-    __syncthreads();
+    lds_barrier();
     if (chunk_sums != nullptr && tid == 0 && s_sum[2] != 0) {
         uint32_t* dst = chunk_sums + 4 * ((size_t)blockIdx.x * PL_POOL / SCAN_TILE);
         if (s_sum[0]) { atomicAdd(dst, s_sum[0]); atomicAdd(dst + 1, s_sum[1]); }

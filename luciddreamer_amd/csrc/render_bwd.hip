@@ -71,7 +71,8 @@ __device__ __forceinline__ void reduce8(float& a0, float a1, float a2, float a3,
                  "s_nop 0\n\t"
                  "v_permlane16_swap_b32 %4, %6\n\t"
                  "v_add_f32 %0, %0, %2\n\t"
-                 "v_add_f32 %4, %4, %6"
+                 "v_add_f32 %4, %4, %6\n\t"
+                 "s_nop 1"                                  // whatever follows may be a DPP read of %0 / %4 (two wait states)
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3));
 }
 // Finish the wave reduction inside the 16-lane rows with the terms kept TRANSPOSED: instead of three independent row sums
@@ -87,8 +88,7 @@ __device__ __forceinline__ void reduce8(float& a0, float a1, float a2, float a3,
 // row_mirror idiom measured no different, profiles/r03b_ab_bwd_red_dpp_store.json.)
 __device__ __forceinline__ float row_merge3(float ra, float rb, float sB)
 {
-    asm volatile("s_nop 1\n\t"
-                 "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"        // db: l + (l ^ 8)
+    asm volatile("v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"        // db: l + (l ^ 8); reduce8 ends with the wait
                  "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"        // lanes 8-15: rb[l] + rb[l-8]
                  "v_add_f32_dpp %1, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"        // lanes 0-7:  ra[l] + ra[l+8]
                  "v_add_f32_dpp %2, %2, %2 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"        // lanes 4-7, 12-15: db[l] + db[l-4]
@@ -240,7 +240,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 
     // block-uniform: the deepest contributor of any pixel in the tile; batches entirely behind it are skipped
     if (l == 0) s_wlast[w] = wave_last;
-    __syncthreads();
+    lds_barrier();
     uint32_t tile_last = 0;
 #pragma unroll
     for (int i = 0; i < NWAVES; i++) tile_last = max(tile_last, s_wlast[i]);
@@ -267,7 +267,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             }
             continue;
         }
-        __syncthreads();                                  // previous batch fully consumed / flushed
+        lds_barrier();                                  // previous batch fully consumed / flushed
         if (tid < cnt) {
             const uint32_t e = point_list[range.x + (pos_hi - tid)];     // emission index of this instance
             s_hit[tid] = quad_hits[range.x + (pos_hi - tid)];
@@ -285,7 +285,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 #pragma unroll
                 for (int k = 0; k < 12; k++) s_acc[tid][a][k] = 0.f;
         }
-        __syncthreads();
+        lds_barrier();
 
         for (int sb = 0; sb < cnt; sb += 64) {
             // CULL: lane l takes staged Gaussian sb+l (list position pos_hi-(sb+l)): the forward's quadrant tests (byte q of
@@ -341,7 +341,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < cnt) {
             // every instance owns one 48-byte slot: plain stores, no atomics, and the per-Gaussian sum in
             // k_gauss_bwd runs in a fixed order (the slot is written even when nothing contributed).  The factors that

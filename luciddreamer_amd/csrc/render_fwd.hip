@@ -101,7 +101,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     for (int base = 0; base < total; base += BATCH) {
         // all quadrants finished?  (also the barrier that protects the LDS planes of the previous batch)
         if (l == 0) s_wdone[w] = wave_done ? 1 : 0;
-        __syncthreads();
+        lds_barrier();
         if (s_wdone[0] + s_wdone[1] + s_wdone[2] + s_wdone[3] == NWAVES) break;
         const int cnt = min(BATCH, total - base);
         if (tid < cnt) {
@@ -113,7 +113,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
         }
-        __syncthreads();
+        lds_barrier();
         if (wave_done) continue;
 
         for (int sb = 0; sb < cnt; sb += 64) {

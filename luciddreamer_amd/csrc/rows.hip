@@ -27,9 +27,9 @@ __device__ __forceinline__ uint32_t rs_block_sum(uint32_t v, uint32_t* s_tmp)
 {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    __syncthreads();
+    lds_barrier();
     if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     return s_tmp[0] + s_tmp[1] + s_tmp[2] + s_tmp[3];
 }
 
@@ -79,7 +79,7 @@ k_mask_rank(int P, const uint8_t* __restrict__ mask, const uint32_t* __restrict_
     }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) s_wave[w] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t wbase = 0;
     for (int i = 0; i < w; i++) wbase += s_wave[i];
     uint32_t run = pre + wbase + inc - sum;
@@ -108,7 +108,7 @@ k_gather_rows(int P, const uint8_t* __restrict__ mask, const uint32_t* __restric
         const int i = base + r;
         s_rank[r] = (i < P && mask[i] != 0) ? rank[i] : 0xFFFFFFFFu;
     }
-    __syncthreads();
+    lds_barrier();
     const uint32_t w = T.row_words[t];
     const uint32_t* __restrict__ src = T.src[t] + (size_t)base * w;
     uint32_t* __restrict__ dst = T.dst[t];

@@ -50,10 +50,10 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
     if ((threadIdx.x & 63) == 0) s_tmp[threadIdx.x >> 6] = v;
-    __syncthreads();
+    lds_barrier();
     uint32_t t = 0;
     for (int i = 0; i < (int)(blockDim.x >> 6); i++) t += s_tmp[i];
-    __syncthreads();
+    lds_barrier();
     return t;
 }
 
@@ -96,7 +96,7 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
     }
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) { s_wc[w] = inc_c; s_wi[w] = inc_i; }
-    __syncthreads();
+    lds_barrier();
     uint32_t wb_c = 0, wb_i = 0;
     for (int i = 0; i < w; i++) { wb_c += s_wc[i]; wb_i += s_wi[i]; }
     uint32_t run_c = pre_c + wb_c + inc_c - sum_c;
@@ -262,7 +262,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
     __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < bins; i += PART_THREADS) s_bin[bin_slot(i)] = bin_total[i];
-    __syncthreads();
+    lds_barrier();
     const int base = threadIdx.x * PER;
     uint32_t v[PER];
     uint32_t sum = 0;
@@ -275,7 +275,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
         if (lane >= off) inc += t;
     }
     if (lane == 63) s_wave[w] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t run = inc - sum;
     for (int j = 0; j < w; j++) run += s_wave[j];
     if (threadIdx.x == PART_THREADS - 1) s_total = run + sum;
@@ -291,9 +291,9 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
             const uint32_t t = __shfl_up(binc, off);
             if (lane >= off) binc += t;
         }
-        __syncthreads();                                  // s_wave is reused
+        lds_barrier();                                  // s_wave is reused
         if (lane == 63) s_wave[w] = binc;
-        __syncthreads();
+        lds_barrier();
         q = binc - nbig;
         for (int j = 0; j < w; j++) q += s_wave[j];
     }
@@ -307,7 +307,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
         run += v[i];
     }
     if (publish && threadIdx.x == PART_THREADS - 1) big_queue[0] = q;
-    __syncthreads();
+    lds_barrier();
     // coalesced pass: starts (and the next bin's start = this bin's end) out of LDS, this workgroup's row from global
     for (int i0 = 0; i0 < bins; i0 += PART_THREADS) {
         const int i = i0 + threadIdx.x;
@@ -317,7 +317,7 @@ __device__ __forceinline__ void bin_prefix_to_lds(int bins, int num_tiles, int s
             en = (i + 1 < bins) ? s_bin[bin_slot(i + 1)] : s_total;
             r = row[i];
         }
-        __syncthreads();                                  // every start of this sweep is read before any is advanced
+        lds_barrier();                                  // every start of this sweep is read before any is advanced
         if (i < bins) {
             s_bin[bin_slot(i)] = st + r;
             if (publish) {
@@ -355,7 +355,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
 #endif
         bin_prefix_to_lds(bins, gx * gy, sub_shift, bin_total, row, s_bin, b == 0, bin_start, ranges, big_queue);
     }
-    __syncthreads();
+    lds_barrier();
     uint32_t beg, end;
     part_chunk(V, nb, b, beg, end);
     const uint32_t sub_mask = (1u << sub_shift) - 1u;
@@ -364,7 +364,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
                    [&](uint32_t tile, uint32_t slot, uint32_t gid, uint32_t) {
                        if (slot < cap) { atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u); inst_gid[slot] = gid; }
                    });
-        __syncthreads();
+        lds_barrier();
         for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[bin_slot(i)];
     } else {
         walk_chunk(beg, end, gx, gy, own_max, vis_list, offsets, hitrec, rec, radii,
@@ -406,7 +406,7 @@ k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict_
 #pragma unroll
     for (int i = 0; i < SCAN1_ROWS; i++) sum += v[i];
     s_tot[g][bl] = sum;
-    __syncthreads();
+    lds_barrier();
     uint32_t run = 0, total = 0;
 #pragma unroll
     for (int j = 0; j < SCAN1_GROUPS; j++) { const uint32_t t = s_tot[j][bl]; if (j < g) run += t; total += t; }
@@ -506,10 +506,10 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
         const uint32_t n = bin_total[bin];
         if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_GROUP_LDS) continue;
         const uint32_t start = bin_start[bin];
-        __syncthreads();
+        lds_barrier();
         for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
-        __syncthreads();
-        bitonic_sort(s_a, n, threadIdx.x, 256u, [] { __syncthreads(); });
+        lds_barrier();
+        bitonic_sort(s_a, n, threadIdx.x, 256u, [] { lds_barrier(); });
         write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
     }
 }
@@ -538,18 +538,18 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
     const int bin = (int)big_queue[1 + qi];
     const uint32_t n = bin_total[bin];
     const uint32_t start = bin_start[bin];
-    __syncthreads();
+    lds_barrier();
     if (n > (uint32_t)TSORT_MID_LDS) {
         if (n <= lds_entries) {
             for (uint32_t i = tid; i < n; i += TSORT_THREADS) s_out[i] = words[start + i];
-            __syncthreads();
-            bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+            lds_barrier();
+            bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { lds_barrier(); });
             write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
         } else {
             // larger than the LDS of this launch: the same network in place in global memory (one workgroup, L2-resident;
             // slow, but a single tile with that many splats is slow to blend anyway)
             unsigned long long* a = words + start;
-            bitonic_sort(a, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __threadfence(); __syncthreads(); });
+            bitonic_sort(a, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __threadfence(); lds_barrier(); });
             write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
         }
         continue;
@@ -571,7 +571,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
         kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
     }
     if (lane == 0) { s_red[2 * w] = kmin; s_red[2 * w + 1] = kmax; }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < TSORT_THREADS / 64; i++) { kmin = s_red[2 * i] < kmin ? s_red[2 * i] : kmin; kmax = s_red[2 * i + 1] > kmax ? s_red[2 * i + 1] : kmax; }
     // bucket of a key: floor((key - kmin) * nbuckets / (span + 1)), evaluated in double (span < 2^34: exact enough to be
@@ -587,7 +587,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
         bucket[k] = bk < nb ? bk : nb - 1;
         if (i < n) atomicAdd(&s_cnt[bucket[k]], 1u);
     }
-    __syncthreads();
+    lds_barrier();
     // exclusive scan of the bucket counts: thread t owns buckets [t*PER, t*PER+PER)
     uint32_t c[PER], sum = 0;
 #pragma unroll
@@ -599,21 +599,21 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
         if (lane >= off) inc += t;
     }
     if (lane == 63) s_wave[w] = inc;
-    __syncthreads();
+    lds_barrier();
     uint32_t run = inc - sum;
     for (int j = 0; j < w; j++) run += s_wave[j];
     const uint32_t my_first = run;
 #pragma unroll
     for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += c[k]; }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
         if (i < n) s_out[atomicAdd(&s_cnt[bucket[k]], 1u)] = item[k];
     }
-    __syncthreads();
+    lds_barrier();
     if (s_bad) {
-        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __syncthreads(); });
+        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { lds_barrier(); });
     } else {
         // each thread orders its own PER consecutive buckets: the segment [my_first, run)
         uint32_t lo = my_first;
@@ -628,7 +628,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
             }
             lo = hi;
         }
-        __syncthreads();
+        lds_barrier();
     }
     write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
     }

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own"):
         _lib.tune_set(k, -1)
 
 
@@ -139,3 +139,44 @@ def test_compiled_node_accumulates_into_existing_grads_and_checks_versions(hip_d
         p["scales"].mul_(1.0)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         (color * g).sum().backward()
+
+
+@pytest.mark.parametrize("kind,P,W,H,scale_mult", [("band", 60_000, 640, 360, 1.0), ("box", 4_000, 800, 450, 6.0)])
+def test_binning_walks_with_and_without_hit_masks_agree(hip_device, kind, P, W, H, scale_mult):
+    """The binning walks a Gaussian's instances from the bit mask preprocess leaves (common.h HitRec; rectangles of up to 64
+    tiles whose origin fits the record) or, without one, from its record, repeating the tile test (rectangles of 65-96 tiles,
+    everything on tile grids beyond 4096).  lr_tune_set("hit_mask", 0) takes the masks away from every Gaussian: same lists,
+    same images, same gradients, bit for bit.  The second scene has splats that cover hundreds of tiles (unculled walk)."""
+    cloud = synthetic.make_cloud(P, kind, 5, scale_mult=scale_mult)
+    cam = cameras.rotate360_path(W, H, n_views=30)[9] if kind == "band" else cameras.identity_camera(W, H)
+    g = synthetic.upstream_grad(H, W)
+    outs = []
+    try:
+        for v in (-1, 0):
+            _lib.tune_set("hit_mask", v)
+            outs.append(_run(cloud, cam, hip_device, g))
+    finally:
+        _lib.tune_set("hit_mask", -1)
+    a, b = outs
+    assert np.array_equal(a["radii"], b["radii"])
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    ref = hp.run_oracle(cloud, cam, 3, torch.zeros(3), g)
+    hp.compare_forward(a, ref, max_fragile=max(8, 1e-3 * W * H))      # huge splats: heavy overdraw, many pixels near a threshold
+
+
+@pytest.mark.parametrize("W,H", [(640, 360), (1280, 720)])      # quadrant-per-wave shape / two-wave shape of k_render_bwd
+@pytest.mark.parametrize("red", [0, 1])
+def test_backward_is_bit_repeatable_over_many_runs(hip_device, W, H, red):
+    """Forty runs of the same view give the same gradients, bit for bit, with either reduction.  This is the test that would
+    have caught the missing `s_waitcnt lgkmcnt(0)` in front of the barrier that closes a batch of k_render_bwd (common.h
+    lds_barrier): with the LDS-atomic reduction one Gaussian's colour gradient differed in ~5 % of the runs."""
+    cam, cloud = hp.box_setup(40_000, W, H)
+    g = synthetic.upstream_grad(H, W)
+    _lib.tune_set("bwd_red", red)
+    first = _run(cloud, cam, hip_device, g)
+    for _ in range(40):
+        again = _run(cloud, cam, hip_device, g)
+        for k in first["grads"]:
+            assert np.array_equal(again["grads"][k], first["grads"][k]), k
