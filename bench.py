@@ -567,6 +567,44 @@ def run_cpu_baseline(wl):
                 key = "this_rasterizer" if be == "ours" else "reference_kernels_on_this_gpu"
                 out[key] = {"iter_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3),
                             "final_loss": round(float(res["loss"][-1]), 5)}
+            # the same iteration with the optional pieces of SURVEY.md section 8f switched in (one line
+            # each in the reference's loop): render_raw (activations inside the kernels), the fused L1+DSSIM loss, the
+            # fused Adam step and densification statistics -- same cloud, cameras, targets, view order and loss terms
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("lr_example_train_loop", os.path.join(ROOT, "examples", "train_loop.py"))
+            ex = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(ex)
+            from luciddreamer_amd import densify
+            from luciddreamer_amd.gaussian_renderer import render_raw
+            from luciddreamer_amd.loss import l1_dssim_loss
+            dev = torch.device("cuda:0")
+            cams_d = [c.to(dev) for c in cams]
+            tg, dg = [t.to(dev) for t in targets], [t.to(dev) for t in depths]
+            bg = torch.zeros(3, device=dev)
+            for _pass in range(2):                                # first pass: warm-up, as above
+                b = {k: v.to(dev) for k, v in base.items()}
+                model = ex.TrainableCloud(b["means3D"], b["scales"], b["rotations"], b["opacities"], b["shs"])
+                model.training_setup({"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3,
+                                      "rotation": 1e-3})
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for it in range(iters):
+                    k = order[it]
+                    pkg = render_raw(cams_d[k], model, bg_color=bg)
+                    loss = l1_dssim_loss(pkg["render"], tg[k], 0.2) + 0.1 * (pkg["depth"] - dg[k]).abs().mean()
+                    loss.backward()
+                    with torch.no_grad():
+                        densify.add_densification_stats(model, pkg["viewspace_points"], pkg["radii"])
+                        model.optimizer.step()
+                        model.optimizer.zero_grad(set_to_none=True)
+                    last = float(loss.detach())                   # the reference loop reads the loss every iteration too
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            out["with_optional_pieces"] = {"iter_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3),
+                                           "final_loss": round(last, 5),
+                                           "what": "render_raw + l1_dssim_loss + FusedAdam + add_densification_stats "
+                                                   "(luciddreamer_amd, SURVEY.md 8f) in place of render / l1+ssim / "
+                                                   "torch.optim.Adam / the mask-indexed statistics"}
             return out
         except Exception as e:
             return {"error": str(e)[:300], "trace": traceback.format_exc()[-600:]}
