@@ -578,7 +578,9 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
                 make_uint2(hit_geo(minx, miny, width, area, vp.hit_origin_limit), __float_as_uint(pj.vz));
             s_mask[i][0] = 0u; s_mask[i][1] = 0u;
             s_mid[5][i] = qmax;                                   // vz is in the record now; the slot carries the threshold
-            s_rect[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16), (uint32_t)width);   // gx, gy <= 65535 (launcher)
+            // gx, gy <= 65535 (launcher); width | reciprocal << 16, the latter only meaningful for tested rectangles (<= 96 tiles)
+            s_rect[i] = make_uint2((uint32_t)minx | ((uint32_t)miny << 16),
+                                   (uint32_t)width | ((tests != 0u ? 32768u / (uint32_t)width + 1u : 0u) << 16));
         }
         s_tests[i0 + tid] = tests;                                // entries between n_mid and the end of the round: zero
     }
@@ -608,7 +610,10 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
             while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_tests[mid] > t) hi = mid; else lo = mid + 1; }
             const uint32_t j = t - (lo ? s_tests[lo - 1] : 0u);
             const uint2 rc = s_rect[lo];
-            const int ty = (int)(rc.x >> 16) + (int)(j / rc.y), tx = (int)(rc.x & 0xffffu) + (int)(j % rc.y);
+            // j / width without a division: (j * (32768 / width + 1)) >> 15 is exact for j < 96, width <= 96 (checked
+            // exhaustively); the reciprocal (<= 32769) rides in the upper half of the width word (phase 3a)
+            const uint32_t wdt = rc.y & 0xffffu, jr = (j * (rc.y >> 16)) >> 15;
+            const int ty = (int)(rc.x >> 16) + (int)jr, tx = (int)(rc.x & 0xffffu) + (int)(j - jr * wdt);
             const float con_a = s_mid[2][lo], con_b = s_mid[3][lo], con_c = s_mid[4][lo];
             const float r_c = -con_b / con_c, r_a = -con_b / con_a;
             if (tile_hit(s_mid[0][lo], s_mid[1][lo], con_a, con_b, con_c, r_c, r_a, s_mid[5][lo], tx, ty)) {

@@ -426,15 +426,21 @@ k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict_
 template <class Sync>
 __device__ __forceinline__ void bitonic_sort(unsigned long long* a, uint32_t n, uint32_t tid, uint32_t nthreads, Sync sync)
 {
-    uint32_t m = 1;
-    while (m < n) m <<= 1;
-    for (uint32_t k = 2; k <= m; k <<= 1) {
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            const bool flip = (j == (k >> 1));
+    // k = 2^lk, j = 2^lj: comparator indices by shifts and masks (`c / j`, `c % j` with run-time operands are ~40-instruction
+    // divisions each: they were most of this kernel's arithmetic)
+    uint32_t lm = 0;
+    while ((1u << lm) < n) lm++;
+    const uint32_t m = 1u << lm;
+    for (uint32_t lk = 1; lk <= lm; lk++) {
+        const uint32_t k = 1u << lk;
+        for (uint32_t lj = lk; lj-- > 0;) {
+            const uint32_t j = 1u << lj;
+            const bool flip = (lj == lk - 1);
             for (uint32_t c = tid; c < (m >> 1); c += nthreads) {
+                const uint32_t hi = c >> lj, lo = c & (j - 1u);
                 uint32_t i, l;
-                if (flip) { i = (c / j) * k + (c % j); l = i ^ (k - 1); }     // mirror inside the block of k
-                else { i = ((c / j) * (j << 1)) + (c % j); l = i + j; }
+                if (flip) { i = (hi << lk) + lo; l = i ^ (k - 1u); }           // mirror inside the block of k
+                else { i = (hi << (lj + 1u)) + lo; l = i + j; }
                 if (l < n) {
                     const unsigned long long x = a[i], y = a[l];
                     if (x > y) { a[i] = y; a[l] = x; }
