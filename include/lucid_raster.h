@@ -375,7 +375,8 @@ int lr_header_poll(long long ticket, int block, unsigned int* out8);
  * milliseconds and the number of recorded calls.  Stage names: lr_profile_stage_name(i).
  * The stages "preprocess", "render_fwd", "render_bwd", "gauss_bwd" are exactly one kernel launch each. */
 /* Diagnostics: switch a kernel variant at run time (benchmark tooling measures two variants alternately in one process).
- * Knobs: "bwd_red" (reduction variant of the blend backward), "blend_quad", "tile_map", "preprocess", "gauss_bwd", "tsort";
+ * Knobs: "bwd_red" (reduction variant of the blend backward), "blend_quad", "tile_map", "preprocess", "gauss_bwd", "tsort",
+ * "walk_own" (instances of a Gaussian the binning walks on its own lane), "hit_mask" (0: binning without preprocess's tile masks);
  * value -1 restores the library's own rule.  Results are identical up to float summation order whatever the setting.
  * Not part of the reference interface (it has no equivalent). */
 int lr_tune_set(const char* name, int value);
