@@ -163,3 +163,29 @@ def test_algorithmic_byte_model_matches_baseline_md():
     b_f, b_b = bench.path_bytes(P, V, R, N, T, K, M)
     assert abs(b_f - 171e6) / 171e6 < 0.02 and abs(b_b - 165e6) / 165e6 < 0.02
     assert bench.stage_bytes("render_bwd", P, V, R, N, T, K, M) == 40 * R + 20 * N + 44 * V
+
+
+def test_division_free_index_arithmetic_of_the_binning_is_exact():
+    """The device code maps bit / pair j of a tile rectangle of width w to (row, column) without an integer division:
+    tilebin.hip walk_chunk uses (j * (65536 / w + 1)) >> 16 for masked rectangles (j < 64, w <= 64, common.h HitRec) and
+    preprocess.hip's pooled count (j * (32768 / w + 1)) >> 15 with the reciprocal packed into 16 bits (j < 96, w <= 96,
+    CULL_MAX_TILES).  Exhaustive check of both, and of the constants they rest on."""
+    text = open(os.path.join(ROOT, "luciddreamer_amd", "csrc", "common.h")).read()
+    assert re.search(r"HIT_MASK_TILES\s*=\s*64\b", text) and re.search(r"CULL_MAX_TILES\s*=\s*96\b", text)
+    for w in range(1, 65):
+        r = 65536 // w + 1
+        assert all((j * r) >> 16 == j // w for j in range(64)), w
+    for w in range(1, 97):
+        r = 32768 // w + 1
+        assert r < 65536 and all((j * r) >> 15 == j // w for j in range(96)), w
+    # bitonic comparator indices by shifts (tilebin.hip bitonic_sort) == the textbook division form
+    for lk in range(1, 8):
+        k = 1 << lk
+        for lj in range(lk - 1, -1, -1):
+            j = 1 << lj
+            for c in range(64):
+                hi, lo = c >> lj, c & (j - 1)
+                if lj == lk - 1:
+                    assert (hi << lk) + lo == (c // j) * k + (c % j)
+                else:
+                    assert (hi << (lj + 1)) + lo == (c // j) * (j << 1) + (c % j)
