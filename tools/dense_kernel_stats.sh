@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summaries of the dense workloads (single stream):  bash tools/gpu_call12.sh <tag>
+# rocprofv3 kernel-trace summaries of the dense workloads (single stream):  bash tools/dense_kernel_stats.sh <tag>
 TAG=${1:-r03z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
