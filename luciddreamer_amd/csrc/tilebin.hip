@@ -471,6 +471,94 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
     }
 }
 
+// One bin of up to THREADS * PER entries, sorted by THREADS threads into s_out: the bucket sort described above k_tile_sort_large.
+// s_cnt: THREADS * PER counters; s_red: 2 words per wave; s_wave: one per wave; s_bad: one flag.  Ends with s_out complete
+// (barrier included).  Any monotone map of the keys onto the buckets keeps the result exact -- the order inside a bucket is
+// made by an insertion sort on the full 64-bit word, a bin whose keys pile up falls back to the bitonic network.
+template <int THREADS, int PER>
+__device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __restrict__ src, uint32_t n, int slot_bits,
+                                                unsigned long long* s_out, uint32_t* s_cnt, unsigned long long* s_red,
+                                                uint32_t* s_wave, uint32_t* s_bad_p)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    unsigned long long item[PER];
+    unsigned long long kmin = ~0ull, kmax = 0ull;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+        item[k] = i < n ? src[i] : ~0ull;
+        if (i < n) { const unsigned long long key = item[k] >> slot_bits; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
+    }
+#pragma unroll
+    for (int k = 0; k < PER; k++) s_cnt[tid + k * THREADS] = 0u;
+    if (tid == 0) *s_bad_p = 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { s_red[2 * w] = kmin; s_red[2 * w + 1] = kmax; }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; i++) { kmin = s_red[2 * i] < kmin ? s_red[2 * i] : kmin; kmax = s_red[2 * i + 1] > kmax ? s_red[2 * i + 1] : kmax; }
+    // bucket of a key: floor((key - kmin) * nbuckets / (span + 1)), evaluated in double (span < 2^34: exact enough to be
+    // monotone, which is all that is needed)
+    uint32_t nb = 1;
+    while (nb < n) nb <<= 1;                                          // <= THREADS * PER
+    const double scale = (double)nb / ((double)(kmax - kmin) + 1.0);
+    uint32_t bucket[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+        uint32_t bk = (uint32_t)((double)((item[k] >> slot_bits) - kmin) * scale);
+        bucket[k] = bk < nb ? bk : nb - 1;
+        if (i < n) atomicAdd(&s_cnt[bucket[k]], 1u);
+    }
+    lds_barrier();
+    // exclusive scan of the bucket counts: thread t owns buckets [t*PER, t*PER+PER)
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { c[k] = s_cnt[tid * PER + k]; sum += c[k]; if (c[k] > 32u) *s_bad_p = 1u; }
+    uint32_t inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[w] = inc;
+    lds_barrier();
+    uint32_t run = inc - sum;
+    for (int j = 0; j < w; j++) run += s_wave[j];
+    const uint32_t my_first = run;
+#pragma unroll
+    for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += c[k]; }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
+        if (i < n) s_out[atomicAdd(&s_cnt[bucket[k]], 1u)] = item[k];
+    }
+    lds_barrier();
+    if (*s_bad_p) {
+        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)THREADS, [] { lds_barrier(); });
+    } else {
+        // each thread orders its own PER consecutive buckets: the segment [my_first, run)
+        uint32_t lo = my_first;
+#pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t hi = lo + c[k];
+            for (uint32_t i = lo + 1; i < hi; i++) {
+                const unsigned long long x = s_out[i];
+                uint32_t j = i;
+                while (j > lo && s_out[j - 1] > x) { s_out[j] = s_out[j - 1]; j--; }
+                s_out[j] = x;
+            }
+            lo = hi;
+        }
+        lds_barrier();
+    }
+}
+
 // Two launches for all bin sizes (round 2 had four, three of which found nothing to do on a sparse view and still cost a
 // launch each):
 //   k_tile_sort_small  256 threads = 4 waves per workgroup.  Part A of the grid: one workgroup per 4 consecutive bins, a bin
@@ -482,11 +570,15 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
 //                      4096 entries the bucket sort, beyond that the bitonic network -- in LDS when the launch was given
 //                      room for it (lds_entries), else in place in global memory.
 __global__ void __launch_bounds__(256)
-k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_tiles, const uint32_t* __restrict__ bin_start,
+k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_tiles, int bucket_b, const uint32_t* __restrict__ bin_start,
                   const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
                   uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
 {
     __shared__ unsigned long long s_a[4 * TSORT_LDS];         // 4 x 256 entries = TSORT_GROUP_LDS
+    __shared__ uint32_t s_cnt[TSORT_GROUP_LDS];               // part B's bucket counters
+    __shared__ unsigned long long s_red[8];
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_bad;
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if ((int)blockIdx.x < groups4) {
         // part A: workgroup g takes bins 4 g .. 4 g + 3, one per wave, if they hold at most 256 entries
@@ -513,9 +605,15 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
         if (n <= (uint32_t)TSORT_LDS || n > (uint32_t)TSORT_GROUP_LDS) continue;
         const uint32_t start = bin_start[bin];
         lds_barrier();
-        for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
-        lds_barrier();
-        bitonic_sort(s_a, n, threadIdx.x, 256u, [] { lds_barrier(); });
+        if (bucket_b) {
+            // the bucket sort of k_tile_sort_large at this size: 4 entries and 4 buckets per thread, ~7 barriers instead of
+            // the network's 45-55
+            bucket_sort_bin<256, TSORT_GROUP_LDS / 256>(words + start, n, slot_bits, s_a, s_cnt, s_red, s_wave, &s_bad);
+        } else {
+            for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
+            lds_barrier();
+            bitonic_sort(s_a, n, threadIdx.x, 256u, [] { lds_barrier(); });
+        }
         write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
     }
 }
@@ -560,82 +658,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
         }
         continue;
     }
-    unsigned long long item[PER];
-    unsigned long long kmin = ~0ull, kmax = 0ull;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
-        item[k] = i < n ? words[start + i] : ~0ull;
-        if (i < n) { const unsigned long long key = item[k] >> slot_bits; kmin = key < kmin ? key : kmin; kmax = key > kmax ? key : kmax; }
-    }
-#pragma unroll
-    for (int k = 0; k < PER; k++) s_cnt[tid + k * TSORT_THREADS] = 0u;
-    if (tid == 0) s_bad = 0u;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const unsigned long long a = __shfl_xor(kmin, off), b = __shfl_xor(kmax, off);
-        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
-    }
-    if (lane == 0) { s_red[2 * w] = kmin; s_red[2 * w + 1] = kmax; }
-    lds_barrier();
-#pragma unroll
-    for (int i = 0; i < TSORT_THREADS / 64; i++) { kmin = s_red[2 * i] < kmin ? s_red[2 * i] : kmin; kmax = s_red[2 * i + 1] > kmax ? s_red[2 * i + 1] : kmax; }
-    // bucket of a key: floor((key - kmin) * nbuckets / (span + 1)), evaluated in double (span < 2^34: exact enough to be
-    // monotone, which is all that is needed)
-    uint32_t nb = 1;
-    while (nb < n) nb <<= 1;                                          // <= TSORT_MID_LDS
-    const double scale = (double)nb / ((double)(kmax - kmin) + 1.0);
-    uint32_t bucket[PER];
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
-        uint32_t bk = (uint32_t)((double)((item[k] >> slot_bits) - kmin) * scale);
-        bucket[k] = bk < nb ? bk : nb - 1;
-        if (i < n) atomicAdd(&s_cnt[bucket[k]], 1u);
-    }
-    lds_barrier();
-    // exclusive scan of the bucket counts: thread t owns buckets [t*PER, t*PER+PER)
-    uint32_t c[PER], sum = 0;
-#pragma unroll
-    for (int k = 0; k < PER; k++) { c[k] = s_cnt[tid * PER + k]; sum += c[k]; if (c[k] > 32u) s_bad = 1u; }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    if (lane == 63) s_wave[w] = inc;
-    lds_barrier();
-    uint32_t run = inc - sum;
-    for (int j = 0; j < w; j++) run += s_wave[j];
-    const uint32_t my_first = run;
-#pragma unroll
-    for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += c[k]; }
-    lds_barrier();
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const uint32_t i = (uint32_t)tid + (uint32_t)k * TSORT_THREADS;
-        if (i < n) s_out[atomicAdd(&s_cnt[bucket[k]], 1u)] = item[k];
-    }
-    lds_barrier();
-    if (s_bad) {
-        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { lds_barrier(); });
-    } else {
-        // each thread orders its own PER consecutive buckets: the segment [my_first, run)
-        uint32_t lo = my_first;
-#pragma unroll
-        for (int k = 0; k < PER; k++) {
-            const uint32_t hi = lo + c[k];
-            for (uint32_t i = lo + 1; i < hi; i++) {
-                const unsigned long long x = s_out[i];
-                uint32_t j = i;
-                while (j > lo && s_out[j - 1] > x) { s_out[j] = s_out[j - 1]; j--; }
-                s_out[j] = x;
-            }
-            lo = hi;
-        }
-        lds_barrier();
-    }
+    bucket_sort_bin<TSORT_THREADS, PER>(words + start, n, slot_bits, s_out, s_cnt, s_red, s_wave, &s_bad);
     write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
     }
 }
@@ -709,8 +732,10 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (t) t->mark(3, s);
     const int groups4 = (pp.bins + 3) / 4;
     const int part_b = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;
+    // lr_tune_set("tsort", 0): bins of 257..1024 entries through the bitonic network (A/B runs); default: bucket sort
+    const int bucket_b = tune_get(TUNE_TSORT) == 0 ? 0 : 1;
     hipLaunchKernelGGL(k_tile_sort_small, dim3(groups4 + part_b), dim3(256), 0, s, pp.bins, groups4, pp.sub_shift, slot_bits,
-                       num_tiles, bin_start, bin_total, words, point_list, ranges);
+                       num_tiles, bucket_b, bin_start, bin_total, words, point_list, ranges);
     // the large bins: LDS for the bucket sort (32 KB of words; three workgroups per CU) unless the AVERAGE bin is already
     // beyond it -- then 128 KB, so that bins of up to 16384 entries are sorted in LDS (a hint for speed only: a bin that
     // does not fit this launch's LDS is sorted in place in global memory).  Capped grid: a sparse view queues nothing

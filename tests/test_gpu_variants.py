@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort"):
         _lib.tune_set(k, -1)
 
 
@@ -180,3 +180,24 @@ def test_backward_is_bit_repeatable_over_many_runs(hip_device, W, H, red):
         again = _run(cloud, cam, hip_device, g)
         for k in first["grads"]:
             assert np.array_equal(again["grads"][k], first["grads"][k]), k
+
+
+def test_mid_size_bins_bucket_sort_and_network_give_the_same_lists(hip_device):
+    """Bins of 257..1024 entries are put in order by a bucket sort (tilebin.hip bucket_sort_bin in k_tile_sort_small) or,
+    with lr_tune_set("tsort", 0), by the bitonic network: the sort word is a total order, so lists, images and gradients are
+    bit-identical.  Dense box cloud at 480 x 272: ~500 instances per tile."""
+    cam, cloud = hp.box_setup(120_000, 480, 272, seed=9)
+    g = synthetic.upstream_grad(272, 480)
+    outs = []
+    try:
+        for v in (-1, 0):
+            _lib.tune_set("tsort", v)
+            outs.append(_run(cloud, cam, hip_device, g))
+    finally:
+        _lib.tune_set("tsort", -1)
+    a, b = outs
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    ref = hp.run_oracle(cloud, cam, 3, torch.zeros(3))
+    hp.compare_forward(a, ref, max_fragile=max(8, 1e-3 * 480 * 272))
