@@ -475,12 +475,12 @@ __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32
 // s_cnt: THREADS * PER counters; s_red: 2 words per wave; s_wave: one per wave; s_bad: one flag.  Ends with s_out complete
 // (barrier included).  Any monotone map of the keys onto the buckets keeps the result exact -- the order inside a bucket is
 // made by an insertion sort on the full 64-bit word, a bin whose keys pile up falls back to the bitonic network.
-template <int THREADS, int PER>
+template <int THREADS, int PER, class Sync>
 __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __restrict__ src, uint32_t n, int slot_bits,
                                                 unsigned long long* s_out, uint32_t* s_cnt, unsigned long long* s_red,
-                                                uint32_t* s_wave, uint32_t* s_bad_p)
+                                                uint32_t* s_wave, uint32_t* s_bad_p, int tid, Sync sync)
 {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = tid >> 6;
     unsigned long long item[PER];
     unsigned long long kmin = ~0ull, kmax = 0ull;
 #pragma unroll
@@ -498,7 +498,7 @@ __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __rest
         kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
     }
     if (lane == 0) { s_red[2 * w] = kmin; s_red[2 * w + 1] = kmax; }
-    lds_barrier();
+    sync();
 #pragma unroll
     for (int i = 0; i < THREADS / 64; i++) { kmin = s_red[2 * i] < kmin ? s_red[2 * i] : kmin; kmax = s_red[2 * i + 1] > kmax ? s_red[2 * i + 1] : kmax; }
     // bucket of a key: floor((key - kmin) * nbuckets / (span + 1)), evaluated in double (span < 2^34: exact enough to be
@@ -514,7 +514,7 @@ __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __rest
         bucket[k] = bk < nb ? bk : nb - 1;
         if (i < n) atomicAdd(&s_cnt[bucket[k]], 1u);
     }
-    lds_barrier();
+    sync();
     // exclusive scan of the bucket counts: thread t owns buckets [t*PER, t*PER+PER)
     uint32_t c[PER], sum = 0;
 #pragma unroll
@@ -526,21 +526,21 @@ __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __rest
         if (lane >= off) inc += t;
     }
     if (lane == 63) s_wave[w] = inc;
-    lds_barrier();
+    sync();
     uint32_t run = inc - sum;
     for (int j = 0; j < w; j++) run += s_wave[j];
     const uint32_t my_first = run;
 #pragma unroll
     for (int k = 0; k < PER; k++) { s_cnt[tid * PER + k] = run; run += c[k]; }
-    lds_barrier();
+    sync();
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const uint32_t i = (uint32_t)tid + (uint32_t)k * THREADS;
         if (i < n) s_out[atomicAdd(&s_cnt[bucket[k]], 1u)] = item[k];
     }
-    lds_barrier();
+    sync();
     if (*s_bad_p) {
-        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)THREADS, [] { lds_barrier(); });
+        bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)THREADS, sync);
     } else {
         // each thread orders its own PER consecutive buckets: the segment [my_first, run)
         uint32_t lo = my_first;
@@ -555,7 +555,7 @@ __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __rest
             }
             lo = hi;
         }
-        lds_barrier();
+        sync();
     }
 }
 
@@ -578,7 +578,7 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
     __shared__ uint32_t s_cnt[TSORT_GROUP_LDS];               // part B's bucket counters
     __shared__ unsigned long long s_red[8];
     __shared__ uint32_t s_wave[4];
-    __shared__ uint32_t s_bad;
+    __shared__ uint32_t s_bad[4];
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     if ((int)blockIdx.x < groups4) {
         // part A: workgroup g takes bins 4 g .. 4 g + 3, one per wave, if they hold at most 256 entries
@@ -587,11 +587,19 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
         if (n == 0 || n > (uint32_t)TSORT_LDS) return;
         unsigned long long* a = s_a + w * TSORT_LDS;
         const uint32_t start = bin_start[bin];
-        for (uint32_t i = l; i < n; i += 64) a[i] = words[start + i];
         // one wave, its own slice: LDS operations of a wave execute in order, so a wave-level fence is all the exchange
         // between its lanes needs (no workgroup barrier anywhere in this part)
         auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+        if (bucket_b == 2 && n > 64) {
+            // the bucket sort by one wave in its own slices (C3: sort stage 19.4 -> 18.5 us, dense 1 M cloud 59.4 -> 56.2;
+            // profiles/r04d_ab_tsort_wave.json); up to 64 entries the network's 21 stages stay cheaper
+            bucket_sort_bin<64, TSORT_LDS / 64>(words + start, n, slot_bits, a, s_cnt + w * TSORT_LDS, s_red + 2 * w, s_wave + w,
+                                                &s_bad[w], l, wsync);
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges);
+            return;
+        }
+        for (uint32_t i = l; i < n; i += 64) a[i] = words[start + i];
         wsync();
         if (n > 1) bitonic_sort(a, n, (uint32_t)l, 64u, wsync);
         write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges);
@@ -608,7 +616,8 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
         if (bucket_b) {
             // the bucket sort of k_tile_sort_large at this size: 4 entries and 4 buckets per thread, ~7 barriers instead of
             // the network's 45-55
-            bucket_sort_bin<256, TSORT_GROUP_LDS / 256>(words + start, n, slot_bits, s_a, s_cnt, s_red, s_wave, &s_bad);
+            bucket_sort_bin<256, TSORT_GROUP_LDS / 256>(words + start, n, slot_bits, s_a, s_cnt, s_red, s_wave, &s_bad[0],
+                                                        (int)threadIdx.x, [] { lds_barrier(); });
         } else {
             for (uint32_t i = threadIdx.x; i < n; i += 256) s_a[i] = words[start + i];
             lds_barrier();
@@ -658,7 +667,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
         }
         continue;
     }
-    bucket_sort_bin<TSORT_THREADS, PER>(words + start, n, slot_bits, s_out, s_cnt, s_red, s_wave, &s_bad);
+    bucket_sort_bin<TSORT_THREADS, PER>(words + start, n, slot_bits, s_out, s_cnt, s_red, s_wave, &s_bad, tid, [] { lds_barrier(); });
     write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
     }
 }
@@ -732,8 +741,9 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (t) t->mark(3, s);
     const int groups4 = (pp.bins + 3) / 4;
     const int part_b = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;
-    // lr_tune_set("tsort", 0): bins of 257..1024 entries through the bitonic network (A/B runs); default: bucket sort
-    const int bucket_b = tune_get(TUNE_TSORT) == 0 ? 0 : 1;
+    // per-bin algorithm: 2 (default) = bucket sort from 65 entries up, 1 = only for 257..1024 (the wave-sized bins through the
+    // bitonic network), 0 = the network for everything up to 1024 (lr_tune_set("tsort", v): A/B runs)
+    const int bucket_b = tune_get(TUNE_TSORT) >= 0 ? tune_get(TUNE_TSORT) : 2;
     hipLaunchKernelGGL(k_tile_sort_small, dim3(groups4 + part_b), dim3(256), 0, s, pp.bins, groups4, pp.sub_shift, slot_bits,
                        num_tiles, bucket_b, bin_start, bin_total, words, point_list, ranges);
     // the large bins: LDS for the bucket sort (32 KB of words; three workgroups per CU) unless the AVERAGE bin is already

@@ -190,14 +190,15 @@ def test_mid_size_bins_bucket_sort_and_network_give_the_same_lists(hip_device):
     g = synthetic.upstream_grad(272, 480)
     outs = []
     try:
-        for v in (-1, 0):
+        for v in (-1, 1, 0):          # default (bucket sort from 65 entries), bucket sort from 257, network only
             _lib.tune_set("tsort", v)
             outs.append(_run(cloud, cam, hip_device, g))
     finally:
         _lib.tune_set("tsort", -1)
-    a, b = outs
-    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
-    for k in a["grads"]:
-        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+        for k in a["grads"]:
+            assert np.array_equal(a["grads"][k], b["grads"][k]), k
     ref = hp.run_oracle(cloud, cam, 3, torch.zeros(3))
     hp.compare_forward(a, ref, max_fragile=max(8, 1e-3 * 480 * 272))
