@@ -187,8 +187,9 @@ constexpr uint32_t CULL_MAX_TILES = 96;       // larger rectangles are emitted u
 
 // Minimum-of-quadratic test on an axis-aligned box of pixel centres [x_lo,x_hi] x [y_lo,y_hi].
 // r_c = -cb/cc and r_a = -cb/ca are the slopes of the edge-constrained minimisers (one division each per
-// Gaussian, not per box).  Evaluated by k_preprocess (count), k_emit (emission) -- which must agree bit for
-// bit whatever the contraction setting of the translation unit -- and by the blend kernels per 8x8 quadrant.
+// Gaussian, not per box).  Evaluated by the preprocess kernels (count + tile mask) and by the binning walk for
+// rectangles without a mask -- which must agree bit for bit whatever the contraction setting of the translation
+// unit -- and by the blend forward per 8x8 quadrant (the backward reads the forward's outcome back).
 __device__ __forceinline__ bool box_hit(float mx, float my, float ca, float cb, float cc, float r_c, float r_a,
                                         float qmax, float x_lo, float x_hi, float y_lo, float y_hi)
 {

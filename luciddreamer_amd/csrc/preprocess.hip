@@ -3,8 +3,9 @@
 // Replaces FORWARD::preprocess / preprocessCUDA (RAST/cuda_rasterizer/forward.cu:155-256) and
 // checkFrustum (RAST/cuda_rasterizer/rasterizer_impl.cu:54-66).  One streaming pass over the
 // Gaussian attribute arrays: frustum cull, projection, 3D->2D covariance (EWA), conic, radius,
-// tile rectangle, SH->RGB; output is ONE packed 48-byte GaussRec per Gaussian plus the depth sort
-// key -- the reference scatters the same data over seven arrays.
+// tile rectangle, SH->RGB; output is ONE packed 48-byte GaussRec per Gaussian, its instance count after exact tile
+// culling and, for the binning, the outcome of that culling as a bit mask over the tile rectangle (common.h HitRec) --
+// the reference scatters the per-Gaussian data over seven arrays.
 //
 // This translation unit is compiled with -ffp-contract=off: every product/sum is rounded in the
 // operand order the reference source uses (GLM column-major operator order), so that radii, tile

@@ -13,19 +13,22 @@
 //                                        Gaussians (vis_list), each one's first instance slot (offsets, by rank) and
 //                                        every count of the header.  Instance slots are therefore contiguous per
 //                                        Gaussian and ascending with the Gaussian index.
-//   k_part<COUNT>                        a few hundred large workgroups each walk a contiguous chunk of vis_list, run the
-//                                        exact tile test of every rectangle tile and histogram the hits over the
-//                                        partition bins in LDS (one bin per tile up to 16384 tiles; 2^s neighbouring
-//                                        tiles per bin beyond that).  Integer LDS atomics: counts are order-free.
+//   k_part<COUNT>                        a few hundred large workgroups each walk a contiguous chunk of vis_list -- the
+//                                        set bits of the tile mask preprocess left per Gaussian (common.h HitRec; round 3:
+//                                        the walks used to repeat the exact tile test of every rectangle tile) -- and
+//                                        histogram the hits over the partition bins in LDS (one bin per tile up to 16384
+//                                        tiles; 2^s neighbouring tiles per bin beyond that).  Integer LDS atomics: counts
+//                                        are order-free.
 //   k_part_scan1                         per-bin prefix over the workgroups (+ bin totals).
 //   k_part<SCATTER>                      every workgroup first scans the bin totals itself (bin start; workgroup 0 also
 //                                        publishes the per-tile ranges: no identifyTileRanges pass, no memset); then
 //                                        the same walk again; every hit takes the next free position of its bin from
 //                                        an LDS cursor and stores ONE 64-bit word [sub-tile | depth bits | slot].
 //                                        The order inside a bin at this point is arbitrary -- and irrelevant:
-//   k_tile_sort_small / _large           every bin's words are sorted in LDS: <= 256 entries by one wave, <= 1024 by a
-//                                        workgroup (bitonic network), <= 4096 bucket sort, beyond that the network again
-//                                        (in LDS up to 16384 entries when the launch has the room, else in global memory).
+//   k_tile_sort_small / _large           every bin's words are sorted in LDS: <= 256 entries by one wave (bitonic network up
+//                                        to 64, bucket sort above), <= 1024 by a workgroup and <= 4096 by a larger one
+//                                        (bucket sort), beyond that the network (in LDS up to 16384 entries when the
+//                                        launch has the room, else in global memory).
 //                                        The word is a TOTAL order -- depth bits, then slot, and slots ascend with the
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
 //                                        repeatable, whatever order the scatter produced.
@@ -350,9 +353,6 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
     if (MODE == 0) {
         for (int i = threadIdx.x; i < bins + (bins >> 4) + 1; i += PART_THREADS) s_bin[i] = 0u;
     } else {
-#ifdef LR_DBG_NOPROLOGUE
-        if (b == 0)
-#endif
         bin_prefix_to_lds(bins, gx * gy, sub_shift, bin_total, row, s_bin, b == 0, bin_start, ranges, big_queue);
     }
     lds_barrier();
@@ -371,9 +371,6 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
                    [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
                        if (slot < cap) {
                            const uint32_t pos = atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u);
-#ifdef LR_DBG_NOSTORE
-                           if (pos == 0xFFFFFFFFu)
-#endif
                            words[pos] = ((unsigned long long)(tile & sub_mask) << (31 + slot_bits)) |
                                         ((unsigned long long)dbits << slot_bits) | (unsigned long long)slot;
                        }
