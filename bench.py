@@ -635,33 +635,71 @@ def run_cpu_baseline(wl):
     except Exception as e:                                   # optional evidence, never a reason to fail
         out["reference_host_error"] = str(e)[:200]
 
-    # ---- accuracy of the HIP path on view 0 against the oracle (the third part of BASELINE.json's metric)
+    # ---- accuracy of the HIP path against the oracle (the third part of BASELINE.json's metric): views 0 / 11 / 19 of the
+    # path (as many as the workload has), every figure the worst over the views
     parity = None
     try:
-        _, _, res, grads = one_view(oracle, cams[0], keep=True)
-        hip = _hip_one_view(wl, 0)
-        frag = res.stage()["fragile"]
-        fc, fd = (frag & 1) != 0, (frag & 2) != 0
-        cerr = np.abs(hip["color"] - res.color)
-        derr = np.abs(hip["depth"][0] - res.depth[0]) / np.maximum(1.0, np.abs(res.depth[0]))
         names = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")
-        ref_g = dict(zip(names, grads[:8]))
-        gerr = {}
-        for k, a in hip["grads"].items():
-            b = ref_g[k].reshape(a.shape)
-            scale = float(np.abs(b).max())
-            row = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
-            gerr[k] = {"max_rel": float(row.max() / scale) if scale > 0 else float(row.max()),
-                       "rows_above_1e-4": int((row > 1e-4 * scale).sum())}
+        per_view = []
+        for vi in [i for i in (0, 11, 19) if i < len(cams)] or [0]:
+            _, _, res, grads = one_view(oracle, cams[vi], keep=True)
+            hip = _hip_one_view(wl, vi)
+            st = res.stage()
+            frag = st["fragile"]
+            fc, fd = (frag & 1) != 0, (frag & 2) != 0
+            fy, fx = np.nonzero(frag != 0)
+            cerr = np.abs(hip["color"] - res.color)
+            derr = np.abs(hip["depth"][0] - res.depth[0]) / np.maximum(1.0, np.abs(res.depth[0]))
+            ref_g = dict(zip(names, grads[:8]))
+            gerr, all_touch = {}, True
+            for k, a in hip["grads"].items():
+                b = ref_g[k].reshape(a.shape)
+                scale = float(np.abs(b).max())
+                row = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
+                bad = np.nonzero(row > 1e-4 * scale)[0]
+                # a row beyond the tolerance must belong to a splat whose own alpha reaches the 1/255 threshold (to within
+                # 10 %) on a pixel the oracle flags as sitting within float32 rounding of a discrete decision
+                for i in bad:
+                    ca, cb, cc, op = st["conic_opacity"][i].astype(np.float64)
+                    dx, dy = st["means2D"][i, 0] - fx.astype(np.float64), st["means2D"][i, 1] - fy.astype(np.float64)
+                    power = -0.5 * (ca * dx * dx + cc * dy * dy) - cb * dx * dy
+                    all_touch &= bool(((power <= 1e-6) & (op * np.exp(np.minimum(power, 0.0)) >= 0.9 / 255.0)).any())
+                gerr[k] = {"max_rel": float(row.max() / scale) if scale > 0 else float(row.max()), "rows_above_1e-4": int(len(bad))}
+            per_view.append({
+                "view": vi, "max_abs_rgb_err": float(cerr[:, ~fc].max()), "max_abs_rgb_err_unmasked": float(cerr.max()),
+                "max_abs_depth_rel_err": float(derr[~(fc | fd)].max()), "max_abs_depth_rel_err_unmasked": float(derr.max()),
+                "threshold_pixels_flagged_by_oracle": int(fc.sum()), "pixels_above_1e-5_unmasked": int((cerr.max(axis=0) > 1e-5).sum()),
+                "radii_exact": bool(np.array_equal(hip["radii"], res.radii)), "grad_err_vs_tensor_max": gerr,
+                "every_row_above_1e-4_touches_a_flagged_pixel": all_touch})
+            del res, grads, hip
+        worst = lambda key: max(v[key] for v in per_view)
         parity = {
-            "view": "view 0 of the workload, drop-in operator (exact mode) vs the CPU oracle",
-            "max_abs_rgb_err": float(cerr[:, ~fc].max()), "max_abs_rgb_err_unmasked": float(cerr.max()),
-            "max_abs_depth_rel_err": float(derr[~(fc | fd)].max()), "max_abs_depth_rel_err_unmasked": float(derr.max()),
-            "threshold_pixels_flagged_by_oracle": int(fc.sum()), "pixels": int(frag.size),
-            "pixels_above_1e-5_unmasked": int((cerr.max(axis=0) > 1e-5).sum()),
-            "radii_exact": bool(np.array_equal(hip["radii"], res.radii)),
-            "grad_err_vs_tensor_max": gerr, "tolerance": {"rgb": 1e-5, "depth_rel": 1e-5, "grad_rel": 1e-4},
+            "views": [v["view"] for v in per_view], "what": "drop-in operator (exact mode) vs the CPU oracle; worst over the views",
+            "max_abs_rgb_err": worst("max_abs_rgb_err"), "max_abs_rgb_err_unmasked": worst("max_abs_rgb_err_unmasked"),
+            "max_abs_depth_rel_err": worst("max_abs_depth_rel_err"),
+            "max_abs_depth_rel_err_unmasked": worst("max_abs_depth_rel_err_unmasked"),
+            "threshold_pixels_flagged_by_oracle": worst("threshold_pixels_flagged_by_oracle"), "pixels": int(H * W),
+            "pixels_above_1e-5_unmasked": worst("pixels_above_1e-5_unmasked"),
+            "radii_exact": all(v["radii_exact"] for v in per_view),
+            "grad_err_vs_tensor_max": {k: {"max_rel": max(v["grad_err_vs_tensor_max"][k]["max_rel"] for v in per_view),
+                                           "rows_above_1e-4": max(v["grad_err_vs_tensor_max"][k]["rows_above_1e-4"] for v in per_view)}
+                                       for k in per_view[0]["grad_err_vs_tensor_max"]},
+            "every_row_above_1e-4_touches_a_flagged_pixel": all(v["every_row_above_1e-4_touches_a_flagged_pixel"] for v in per_view),
+            "tolerance": {"rgb": 1e-5, "depth_rel": 1e-5, "grad_rel": 1e-4}, "per_view": per_view,
         }
+        cal = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "parity_calibration.json")
+        if os.path.exists(cal):
+            # the budget of those exemptions: how far the reference's own builds are from each other on the same views
+            # (tests/test_gpu_ref_selfcal.py wrote the file on a GPU box; counts only, stamped with the build it was run on)
+            cj = json.load(open(cal))
+            pick = lambda c, pair: None if c.get(pair) is None else {"pixels_beyond_1e-5": c[pair]["pixels_beyond_1e-5"],
+                                                                     "rows_beyond_1e-4": c[pair]["rows_beyond_1e-4"]}
+            parity["reference_self_disagreement"] = {
+                "source": "profiles/parity_calibration.json", "measured_on": cj.get("lr_version"),
+                "cases": {name: {"reference_default_contraction_vs_strict": pick(c, "reference_fma_vs_reference_gfx950"),
+                                 "reference_host_vs_gfx950_strict": pick(c, "reference_host_vs_reference_gfx950"),
+                                 "hip_vs_reference_strict": pick(c, "hip_vs_reference_gfx950")}
+                          for name, c in cj.get("cases", {}).items()}}
     except Exception as e:
         parity = {"error": str(e)[:300], "trace": traceback.format_exc()[-600:]}
 

@@ -23,8 +23,13 @@ instance list reach the caller: the backward kernels of an overflowed view write
                       an overflowed view's image was incomplete and its gradients are zero (device-side guard); the deferred
                       check warns and raises the mark.
   "raise"             Like "drop", but the deferred check raises RuntimeError on a later call or at drain().
+  "recover"           What parallel.ViewStreams runs its views under: never waits while the views are being issued (like
+                      "drop"), but EVERY view's header is examined at end_step() and a view that overflowed -- its
+                      gradients were zero -- is rendered and differentiated again in exact mode before the step returns, so
+                      the step's gradients are those of all its views (`recovered_views` counts them).
 """
 import os
+import threading
 import warnings
 
 
@@ -38,11 +43,18 @@ _calls = 0
 _warm_calls = 2
 _seen = {}           # key -> forwards seen
 _on_overflow = "verify"
-_override = []       # stack of temporary policies (parallel.ViewStreams)
-dropped_views = 0    # views whose gradients were zeroed by the device-side guard (policies "drop" / "raise")
+_tls = threading.local()     # per-thread stack of temporary policies (overflow_policy) and the force-exact depth
+dropped_views = 0    # views whose gradients were zeroed by the device-side guard and NOT made up for (policies "drop" / "raise")
 rerendered_views = 0 # views rendered again in exact mode by the "verify" policy
+recovered_views = 0  # views of a ViewStreams step that overflowed and were run again in exact mode at end_step()
 
-POLICIES = ("verify", "drop", "raise")
+POLICIES = ("verify", "drop", "raise", "recover")
+
+
+def _stack():
+    if not hasattr(_tls, "override"):
+        _tls.override = []
+    return _tls.override
 
 
 def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 1, warm_calls: int = 2,
@@ -75,16 +87,31 @@ class overflow_policy:
         self.policy = policy
 
     def __enter__(self):
-        _override.append(self.policy)
+        _stack().append(self.policy)
         return self
 
     def __exit__(self, *exc):
-        _override.pop()
+        st = _stack()
+        if st:
+            st.pop()
+        return False
+
+
+class force_exact:
+    """Context manager: every forward inside runs in exact mode (the reference's host round trip), whatever the mark says."""
+
+    def __enter__(self):
+        _tls.exact = getattr(_tls, "exact", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _tls.exact -= 1
         return False
 
 
 def current_policy() -> str:
-    return _override[-1] if _override else _on_overflow
+    st = _stack()
+    return st[-1] if st else _on_overflow
 
 
 def set_fused_grad_accumulation(enabled: bool):
@@ -124,6 +151,8 @@ def _digest(words, key, policy):
         _hwm[key] = num_instances
     if trap:
         raise RuntimeError("Point is filtered although prefiltered is set. This shouldn't happen!")
+    if overflow and policy == "recover":
+        return True                       # the owner of the view (parallel.ViewStreams) runs it again
     if overflow and policy != "verify":
         dropped_views += 1
         msg = (f"luciddreamer_amd async mode: a view needed {num_instances} tile instances, more than its binning "
@@ -140,12 +169,13 @@ def _poll(block=False):
     """Examine the completed header copies of "drop" / "raise" forwards, in order."""
     from . import _C
     while _pending:
-        ticket, key, policy = _pending[0]
-        words = _C.header_poll(ticket, block)
+        entry = _pending[0]
+        words = _C.header_poll(entry[0], block)
         if words is None:
             break
         _pending.pop(0)
-        _digest(words, key, policy)
+        entry[3] = None                   # examined even if _digest raises
+        entry[3] = _digest(words, entry[1], entry[2])
 
 
 def drain():
@@ -155,7 +185,7 @@ def drain():
 
 def capacity_for(means3D, rs) -> int:
     """0 = exact mode for this call; otherwise the number of tile instances to size the binning buffer for."""
-    if not _async or means3D.shape[0] == 0:
+    if not _async or means3D.shape[0] == 0 or getattr(_tls, "exact", 0):
         return 0
     _poll()
     key = _key(means3D, rs)
@@ -201,9 +231,9 @@ def note_forward(means3D, rs, num_rendered, geom, capacity):
         return
     global _calls
     _calls += 1
-    if _calls % _CHECK_EVERY:
+    if policy != "recover" and _calls % _CHECK_EVERY:
         return
     from . import _C
     # a 48-byte copy into pinned memory + an event, both owned by the library (lr_header_post): a few microseconds of host
-    # time per view
-    _pending.append([_C.header_post(geom), key, policy])
+    # time per view.  Entry: [ticket, key, policy, overflowed (None until examined)]
+    _pending.append([_C.header_post(geom), key, policy, None])

@@ -300,13 +300,20 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_COUNT };
 int tune_get(int key);
 
-// Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): true = 4 waves per
-// tile, one 8x8 quadrant per wave (small images, latency bound), false = 2 waves per tile, two pixels per lane (issue
-// bound).  LR_BLEND_QUAD_BWD=0/1 forces one (diagnostics).
-bool blend_quad(int num_tiles);
+// Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): BLEND_QUAD = 4 waves per
+// tile, one 8x8 quadrant per wave (small images, latency bound), BLEND_HALF = 2 waves per tile, two pixels per lane,
+// BLEND_TILE = one wave per tile, four pixels per lane (issue bound: the per-candidate reduction is paid once per tile).
+// LR_BLEND_QUAD_BWD=0/1/2 or lr_tune_set("blend_quad", .) forces one (diagnostics).
+enum { BLEND_HALF = 0, BLEND_QUAD = 1, BLEND_TILE = 2 };
+int blend_shape(int num_tiles);
+// Host-side hint: how many views' kernels the caller keeps in flight on different streams (lr_views_accumulate sets it for
+// its own duration; a caller that pipelines the per-view entry points itself -- parallel.ViewStreams -- passes it through
+// lr_tune_set("views_in_flight", n)).  Never a correctness input: it picks between kernel shapes with identical results.
+struct ViewsInFlight { explicit ViewsInFlight(int n); ~ViewsInFlight(); int prev; };
+int views_in_flight();
 // Tile -> workgroup map of the blend kernels.  Workgroup b runs on XCD b % 8 (each XCD has its own L2):
 //   TILE_MAP_BANDS : XCD x renders the contiguous tile band [x T/8, (x+1) T/8): Gaussians that straddle neighbouring tiles
 //                    are re-read from the same L2.

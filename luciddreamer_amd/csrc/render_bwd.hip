@@ -117,13 +117,10 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 // (tools/valu_microbench.hip), so nothing is lost by not packing, and a candidate that failed the exact box test of one
 // quadrant (48 % of them) steps only the other pixel -- half the per-pixel work.  The recursion is branch-free per
 // pixel: a pixel for which the Gaussian is skipped processes it as a layer with alpha = 0 and G = 0, which leaves T,
-// the colour recursion and every gradient term exactly unchanged (T * rcp(1-0) = T; the recursion folds the previous
-// contributor in once, then passes it through with weight 1).
+// the colour recursion and every gradient term exactly unchanged (T * rcp(1-0) = T; A + 0 * d = A).
 struct BwdPix {
     float T;            // transmittance in front of the current layer
     float A;            // (colour seen BEHIND the current layer, background included) . dL/dpixel
-    float last_alpha;   // alpha of the previous (deeper) processed layer ...
-    float lcdl;         // ... and its colour . dL/dpixel
     float dLr, dLg, dLb;
     float pxf;
     uint32_t last;      // list positions below this one were blended by the forward (render_fwd.hip PixState::last)
@@ -134,17 +131,18 @@ struct BwdPix {
 // the list), so ONE scalar A replaces three accumulators, and the background term -T_final/(1-alpha) * bg.dL
 // (backward.cu:556-560) is the last layer of the same recursion (A starts at bg.dL); of the geometric gradients only the
 // moments of D = G * dL/dalpha (D, D dx, D dx^2 here; the dy factors and opacity, conic, -0.5, NDC scale later).
-// FIRST: the lane sums are ASSIGNED (first pixel of the lane for this candidate) instead of accumulated -- `0 + a * b` is
-// not foldable under IEEE rules and would cost an extra v_fma per term next to the product that is needed anyway.
-template <bool FIRST>
+// The layer is folded into A as soon as its gradient is formed: accum_rec' = alpha * colour + (1 - alpha) * accum_rec =
+// A + alpha * (colour.dL - A), and the difference in the bracket is the one dL/dalpha needs anyway (rounds 1-3 carried
+// last_alpha / last colour to the next layer as the reference does and formed the same difference twice: one instruction and
+// two registers per pixel more, same bits).
+// FIRSTM / FIRSTC: the lane's moment / colour sums are ASSIGNED (first pixel of the lane for this candidate) instead of
+// accumulated -- `0 + a * b` is not foldable under IEEE rules and would cost an extra v_fma per term next to the product
+// that is needed anyway.
+template <bool FIRSTM, bool FIRSTC>
 __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float Bd, const float Cdd, const float gx,
                                           const float op, const float cr, const float cg, const float cb, const uint32_t pos,
                                           float& sD, float& sMx, float& sMxx, float& sR, float& sG, float& sB)
 {
-    // fold the previous (deeper) layer into A first: it needs only the carried state, and doing it before this layer's
-    // alpha and colour exist lets them be written straight into the state registers (no register-to-register moves)
-    p.A = p.A + p.last_alpha * (p.lcdl - p.A);                             // = last_alpha * lcdl + (1 - last_alpha) * A
-    asm volatile("" : "+v"(p.A));
     const float dx = gx - p.pxf;
     const float power = gauss_power1(Ap, Bd, Cdd, dx);                     // log2(e) x the reference's power
     const float Graw = gauss_exp2(power);
@@ -157,17 +155,14 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     p.T = p.T * rinv;
     const float dchan = alpha * p.T;
     const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;                // colour of this Gaussian . dL/dpixel
-    p.lcdl = cdl;
-    p.last_alpha = alpha;
-    const float dop = G * ((cdl - p.A) * p.T);                             // G * dL/dalpha
+    const float d = cdl - p.A;
+    const float dop = G * (d * p.T);                                       // G * dL/dalpha
+    p.A = __builtin_fmaf(alpha, d, p.A);                                   // a skipped layer (alpha = 0) leaves A as it is
     const float mx = dop * dx;
-    if (FIRST) {
-        sD = dop; sMx = mx; sMxx = mx * dx;
-        sR = dchan * p.dLr; sG = dchan * p.dLg; sB = dchan * p.dLb;
-    } else {
-        sD += dop; sMx += mx; sMxx += mx * dx;
-        sR += dchan * p.dLr; sG += dchan * p.dLg; sB += dchan * p.dLb;
-    }
+    if (FIRSTM) { sD = dop; sMx = mx; sMxx = mx * dx; }
+    else { sD += dop; sMx += mx; sMxx += mx * dx; }
+    if (FIRSTC) { sR = dchan * p.dLr; sG = dchan * p.dLg; sB = dchan * p.dLb; }
+    else { sR += dchan * p.dLr; sG += dchan * p.dLg; sB += dchan * p.dLb; }
 }
 
 // MERGE: row_merge3 + one plain store per candidate into the wave's own accumulator copy (the default); false = the round-2
@@ -232,7 +227,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     if (insB) { PB.dLr = dL_dpix[pixB]; PB.dLg = dL_dpix[N + pixB]; PB.dLb = dL_dpix[2 * N + pixB]; }
     PA.A = bg[0] * PA.dLr + bg[1] * PA.dLg + bg[2] * PA.dLb;       // background . dL/dpixel: the deepest layer
     PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
-    PA.last_alpha = PA.lcdl = 0.f; PB.last_alpha = PB.lcdl = 0.f;
     const uint32_t lastL = wave_max_u32(PA.last), lastR = QUAD ? 0u : wave_max_u32(PB.last);   // per quadrant
     const uint32_t wave_last = max(lastL, lastR);                   // nothing at or behind this matters to the wave
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
@@ -315,8 +309,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
-                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
@@ -324,7 +318,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 reduce8(ra, sMy, sMxx, sMxy, rb, sD, sR, sG);
                 if (MERGE) {
                     const float rc = row_merge3(ra, rb, sB);
-                    if (merge_writer) (&s_acc[0][0][0])[(uint32_t)j * (12u * NACC) + merge_off] = rc;
+                    int jo = j * (12 * NACC);
+                    asm volatile("" : "+s"(jo));              // scalar product, one v_add for the address (not a v_mad_u64_u32)
+                    if (merge_writer) (&s_acc[0][0][0])[jo + (int)merge_off] = rc;
                 } else {
                     ra = row_sum(ra); rb = row_sum(rb);
                     float rc = row_sum(sB);                           // every row: its partial of db
@@ -366,6 +362,178 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     }
 }
 
+
+// The TILE shape: ONE wave64 per 16x16 tile, a lane owns FOUR pixels -- the same position (l & 7, l >> 3) in each of the
+// tile's four 8x8 quadrants.  What it is for: everything a wave pays per candidate that is not a pixel step -- the LDS reads of
+// the staged element, the loop bookkeeping and above all the cross-lane reduction of the nine sums (29 of ~78 VALU
+// instructions per candidate and wave in the 2-wave shape) -- is paid once per tile instance instead of once per half tile
+// the instance reaches (1.55 at C3, 1.9 on dense clouds); the pixel steps stay per quadrant that passed the forward's box
+// test (2.33 of 4 at C3).  The two rows of quadrants have their own dy, so the lane keeps the moments of the upper and the
+// lower pixel pair apart (D, D dx, D dx^2 each) and applies the dy factors to each pair before the reduction.  Single-wave
+// workgroups: 8160 of them at 1080p, no partner wave to wait for at the batch barriers.
+template <int BATCH>
+__device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
+                  const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
+                  const float* __restrict__ bg, const float* __restrict__ final_Ts,
+                  const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
+                  char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
+{
+    __shared__ float4 s_q0[BATCH];      // as k_render_bwd
+    __shared__ float2 s_q1[BATCH];
+    __shared__ float4 s_q2[BATCH];
+    __shared__ uint32_t s_id[BATCH];
+    __shared__ float s_acc[BATCH * 12]; // one wave, one copy: a candidate is met once per batch, so its sums are plain stores
+
+    const int tile = blend_tile(tile_map, num_tiles);
+    if (tile < 0) return;
+    if (hdr->overflow != 0u) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int l = threadIdx.x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y;
+    const int pxL = x0 + (l & 7), pxR = pxL + 8, pyT = y0 + (l >> 3), pyB = pyT + 8;
+    const float pyTf = (float)pyT, pyBf = (float)pyB;
+    const size_t N = (size_t)W * H;
+
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    if (total == 0) return;
+    const BinLayout BL = bin_layout((long long)hdr->bin_bound);
+    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
+    float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
+    const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
+
+    // quadrant q = x half + 2 * y half (the forward's wave q): P0 upper left, P1 upper right, P2 lower left, P3 lower right
+    BwdPix P0, P1, P2, P3;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    auto load_pixel = [&](BwdPix& p, int px, int py) {
+        const bool ins = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        p.pxf = (float)px;
+        p.T = ins ? final_Ts[pix] : 0.f;
+        p.last = ins ? n_contrib[pix] : 0u;
+        p.dLr = ins ? dL_dpix[pix] : 0.f;
+        p.dLg = ins ? dL_dpix[N + pix] : 0.f;
+        p.dLb = ins ? dL_dpix[2 * N + pix] : 0.f;
+        p.A = bg0 * p.dLr + bg1 * p.dLg + bg2 * p.dLb;
+    };
+    load_pixel(P0, pxL, pyT); load_pixel(P1, pxR, pyT); load_pixel(P2, pxL, pyB); load_pixel(P3, pxR, pyB);
+    const uint32_t last0 = wave_max_u32(P0.last), last1 = wave_max_u32(P1.last);
+    const uint32_t last2 = wave_max_u32(P2.last), last3 = wave_max_u32(P3.last);
+    const uint32_t tile_last = max(max(last0, last1), max(last2, last3));
+    const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
+    const float ddely_dy = (float)(0.5 * H);
+
+    const int row = l >> 4;
+    const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // as k_render_bwd (reduce8 / row_merge3 layout)
+    const int l16 = l & 15;
+    const bool merge_writer = (l16 & 3) == 0 && l16 < 12;
+    const int merge_off = l16 == 0 ? col_a : l16 == 8 ? col_a + 4 : 8 + row;
+
+    for (int base = 0; base < total; base += BATCH) {
+        const int cnt = min(BATCH, total - base);
+        const int pos_hi = total - 1 - base;             // position of staged element 0 (back to front)
+        const int pos_lo = pos_hi - (cnt - 1);
+        if ((uint32_t)pos_lo >= tile_last) {             // whole batch behind every last contributor: slots read as zero
+            if (l < cnt) {
+                float4* slot = inst_grad + 3 * (size_t)point_list[range.x + (pos_hi - l)];
+                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f); slot[1] = slot[0]; slot[2] = slot[0];
+            }
+            continue;
+        }
+        lds_barrier();
+        uint32_t my_hit = 0u;
+        if (l < cnt) {
+            const uint32_t e = point_list[range.x + (pos_hi - l)];
+            my_hit = quad_hits[range.x + (pos_hi - l)];
+            const uint32_t id = inst_gid[e];
+            const float4* g = reinterpret_cast<const float4*>(rec + id);
+            const float4 a = g[0], b = g[1], c = g[2];
+            s_q0[l] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            s_q1[l] = make_float2((-0.5f * LOG2E) * b.x, b.y);
+            s_q2[l] = make_float4(b.z, b.w, c.x, 0.f);
+            s_id[l] = e;
+        }
+        if (l < BATCH) {
+            float4* z = reinterpret_cast<float4*>(&s_acc[l * 12]);
+            z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
+        }
+        lds_barrier();
+
+        // CULL: the staging lane IS the lane that holds the element's quadrant tests (one batch = one wave-wide chunk)
+        const uint32_t pos_l = (uint32_t)(pos_hi - l);
+        const bool inb = l < cnt;
+        const uint64_t m0 = __ballot(inb && pos_l < last0 && (my_hit & 0x000000ffu) != 0u);
+        const uint64_t m1 = __ballot(inb && pos_l < last1 && (my_hit & 0x0000ff00u) != 0u);
+        const uint64_t m2 = __ballot(inb && pos_l < last2 && (my_hit & 0x00ff0000u) != 0u);
+        const uint64_t m3 = __ballot(inb && pos_l < last3 && (my_hit & 0xff000000u) != 0u);
+        uint64_t mask = (m0 | m1) | (m2 | m3);
+        while (mask) {
+            const int j = __ffsll((long long)mask) - 1;       // staged order is already back to front
+            mask &= mask - 1;
+            const uint32_t pos = (uint32_t)(pos_hi - j);
+            const float4 a = s_q0[j];
+            const float2 b = s_q1[j];                         // Cp, opacity
+            const float4 c = s_q2[j];
+            const float dysT = a.y - pyTf, dysB = a.y - pyBf;
+            float tD = 0.f, tMx = 0.f, tMxx = 0.f, bD = 0.f, bMx = 0.f, bMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
+            const bool h0 = (m0 >> j) & 1ull, h1 = (m1 >> j) & 1ull, h2 = (m2 >> j) & 1ull, h3 = (m3 >> j) & 1ull;
+            if (h0 || h1) {
+                const float Bd = a.w * dysT, Cdd = (b.x * dysT) * dysT;                        // common.h gauss_power
+                if (h0) bwd_pixel<true, true>(P0, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h1) bwd_pixel<false, false>(P1, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+            }
+            if (h2 || h3) {
+                const float Bd = a.w * dysB, Cdd = (b.x * dysB) * dysB;
+                if (h2) bwd_pixel<true, false>(P2, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h3) bwd_pixel<false, false>(P3, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+            }
+            // the dy factors, per pixel pair (a pair shares its row)
+            const float t1 = dysT * tD, t2 = dysB * bD;
+            const float sD = tD + bD, sMxx = tMxx + bMxx;
+            const float sMy = t1 + t2;
+            const float sMxy = dysT * tMx + dysB * bMx;
+            const float sMyy = dysT * t1 + dysB * t2;
+            float ra = tMx + bMx, rb = sMyy;
+            reduce8(ra, sMy, sMxx, sMxy, rb, sD, sR, sG);
+            const float rc = row_merge3(ra, rb, sB);
+            int jo = j * 12;
+            asm volatile("" : "+s"(jo));                      // scalar product, one v_add for the address (not a v_mad_u64_u32)
+            if (merge_writer) s_acc[jo + merge_off] = rc;
+        }
+        lds_barrier();
+        if (l < cnt) {
+            float a9[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) a9[k] = s_acc[l * 12 + k];
+            const float4 q0 = s_q0[l]; const float2 q1 = s_q1[l];
+            const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
+            const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;
+            const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
+            float4* slot = inst_grad + 3 * (size_t)s_id[l];
+            slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
+            slot[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
+            slot[2] = make_float4(db, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+#define LR_BWD_PARAMS int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,                   \
+                      const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,                        \
+                      const float* __restrict__ bg, const float* __restrict__ final_Ts,                                 \
+                      const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,                        \
+                      char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr
+#define LR_BWD_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr
+// 64 VGPRs and 4.3 KB of LDS: 8 waves per SIMD, so the 8160 waves of a 1080p view are all resident at once (8192 slots).  The
+// tiles of a view carry nearly the same load (C3: 70 instances on average, 102 at most): with 7 per SIMD the last 992 waves
+// start when the first 7168 finish together and then run alone on their SIMDs, one instruction per ~5 cycles.
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_vgpr(64)))
+k_render_bwd_tile(LR_BWD_PARAMS) { render_bwd_tile<48>(LR_BWD_PASS); }
+// the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
+k_render_bwd_tile7(LR_BWD_PARAMS) { render_bwd_tile<64>(LR_BWD_PASS); }
+#undef LR_BWD_PARAMS
+#undef LR_BWD_PASS
+
 }  // namespace
 
 int blend_tile_map(int num_tiles)
@@ -376,17 +544,29 @@ int blend_tile_map(int num_tiles)
     return num_tiles <= 4096 ? TILE_MAP_PLAIN : TILE_MAP_BANDS;
 }
 
-bool blend_quad(int num_tiles)
+static thread_local int g_views_in_flight = 1;
+ViewsInFlight::ViewsInFlight(int n) : prev(g_views_in_flight) { g_views_in_flight = n; }
+ViewsInFlight::~ViewsInFlight() { g_views_in_flight = prev; }
+int views_in_flight() { return max(g_views_in_flight, tune_get(TUNE_VIEWS_IN_FLIGHT)); }
+
+int blend_shape(int num_tiles)
 {
     static const int forced = [] { const char* e = getenv("LR_BLEND_QUAD_BWD"); return e ? atoi(e) : -1; }();
-    if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD) != 0;
-    if (forced >= 0) return forced != 0;
-    // The backward blend pays its cross-lane reduction per wave and candidate, so the 2-wave shape (a wave owns two
-    // quadrants and reduces once for both) wins once 2 waves per tile come near filling the 1024 SIMDs x 7 wave slots;
-    // below that every workgroup is resident at once, the kernel time is the longest per-wave chain, and the quadrant
-    // shape shortens it (dense 1 M cloud, single view: 256^2 0.22 -> 0.13 ms, 512^2 0.51 -> 0.42, 800^2 0.58 -> 0.53,
-    // 1024^2 equal, 1280x720 0.42 -> 0.44)
-    return num_tiles <= 3072;
+    if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD);
+    if (forced >= 0) return forced;
+    // The backward blend pays its cross-lane reduction per wave and candidate.  Small images (every workgroup resident at once:
+    // the kernel time is the longest per-wave chain): the quadrant shape shortens the chain (dense 1 M cloud, single view:
+    // 256^2 0.22 -> 0.13 ms, 512^2 0.51 -> 0.42, 800^2 0.58 -> 0.53, 1024^2 equal, 1280x720 0.42 -> 0.44).
+    if (num_tiles <= 3072) return BLEND_QUAD;
+    // Large images, measured on MI355X (profiles/r04a_ab_bwd_shape.json, r04b_ab_bwd_tile8.json; us single stream / views/s
+    // with three views in flight, 2-wave shape -> one wave per tile): C3 91.7 -> 96.0 us but 5020-5160 -> 5200-5245 views/s;
+    // dense 1 M cloud 466 -> 458 us, 1110-1124 -> 1163-1166 views/s; 3 M / 1440p 896 -> 896 us, 454-461 -> 460-467 views/s.
+    // The TILE shape issues 1.5 % fewer VALU instructions and 3.2 % fewer VALU cycles (PMC: 48.66 M -> 47.9 M instructions,
+    // SQ_ACTIVE_INST_VALU 54.3 M -> 52.6 M per C3 launch: the reduction's swaps and DPP adds are paid per tile instance
+    // instead of per half tile reached, the dy bookkeeping it adds is plain multiplies), but its 8160 waves -- all resident
+    // at once, all in the same phase -- expose their staging latencies together when the kernel has the GPU to itself.  So:
+    // one wave per tile when other views' kernels fill those gaps, the 2-wave shape for a lone view.
+    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_HALF;
 }
 
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
@@ -409,7 +589,11 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const int red = tune_get(TUNE_BWD_RED) >= 0 ? tune_get(TUNE_BWD_RED) : forced_red;
     const bool merge = red != 0;
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr
-    if (blend_quad(num_tiles)) {
+    const int shape = blend_shape(num_tiles);
+    if (shape == BLEND_TILE) {
+        if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
+        else hipLaunchKernelGGL(k_render_bwd_tile, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
+    } else if (shape == BLEND_QUAD) {
         if (merge) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
         else hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
     } else {

@@ -317,36 +317,49 @@ class ViewStreams:
         self._caller = None
 
     def begin_step(self):
-        from . import config
+        from . import _lib, config
+        if getattr(self, "_policy", None) is not None:       # a step that never reached end_step() (exception in user code)
+            self._pop_policy()
         cur = torch.cuda.current_stream(self.device)
         for s in self.streams:
             s.wait_stream(cur)
         self._prev_bwd = None
         self._caller = cur
-        # several views in flight: a forward must not wait for its own header copy (config "verify" does); an
-        # overflowed view contributes zero gradients and is reported by the deferred check instead
-        config._override.append("drop")
-        self._policy_pushed = True
+        # several views in flight: a forward must not wait for its own header copy (config "verify" does).  "recover": every
+        # view's header is examined at end_step() and a view that overflowed its binning buffer -- the device-side guard
+        # zeroed its gradients -- is run again in exact mode there, so no view of the step is lost
+        self._policy = config.overflow_policy("recover")
+        self._policy.__enter__()
+        self._views = []
+        self.recovered = 0
+        # kernel shapes for a GPU shared by several views (render_bwd.hip blend_shape); never a correctness input
+        _lib.tune_set("views_in_flight", len(self.streams))
 
     def _pop_policy(self):
-        from . import config
-        if getattr(self, "_policy_pushed", False):
-            config._override.pop()
-            self._policy_pushed = False
+        from . import _lib
+        if getattr(self, "_policy", None) is not None:
+            self._policy.__exit__(None, None, None)
+            self._policy = None
+            _lib.tune_set("views_in_flight", -1)
 
     def run_view(self, forward_fn: Callable, backward_fn: Callable):
+        from . import config
         s = self.streams[self._i % len(self.streams)]
         # set_stream instead of the `with torch.cuda.stream(s)` context: the context manager's save / restore per view is
         # ~10 us of host time on a path that is host bound; end_step() puts the caller's stream back
         torch.cuda.set_stream(s)
         try:
+            n0 = len(config._pending)
             out = forward_fn()
+            entry = config._pending[-1] if len(config._pending) > n0 else None      # this view's header copy, if async
             if self._prev_bwd is not None:
                 s.wait_event(self._prev_bwd)
             backward_fn(out)
             ev = self._events[self._i % len(self._events)]
             ev.record(s)
             self._prev_bwd = ev
+            if entry is not None:
+                self._views.append((entry, forward_fn, backward_fn))
         except BaseException:
             if self._caller is not None:
                 torch.cuda.set_stream(self._caller)
@@ -355,12 +368,29 @@ class ViewStreams:
         self._i += 1
 
     def end_step(self):
+        from . import config
         cur = self._caller if self._caller is not None else torch.cuda.current_stream(self.device)
         torch.cuda.set_stream(cur)
         for s in self.streams:
             cur.wait_stream(s)
         self._caller = None
-        self._pop_policy()
+        views, self._views = getattr(self, "_views", []), []
+        try:
+            if views:
+                # The header copies complete when the LAST view's compaction scan has run -- its blend and backward are still
+                # queued behind, so the GPU stays busy while the host looks.  A view whose instance count exceeded its
+                # buffer contributed zero gradients; it is run again here, exact mode, on the caller's stream.
+                config.drain()
+                lost = [v for v in views if v[0][3]]
+                if lost:
+                    with config.force_exact(), config.overflow_policy("verify"):
+                        for _, fwd, bwd in lost:
+                            bwd(fwd())
+                    self.recovered = len(lost)
+                    config.recovered_views += len(lost)
+        finally:
+            self._pop_policy()
+        return self.recovered
 
 
 class ViewBatch:

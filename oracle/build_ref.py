@@ -84,14 +84,20 @@ def build(force=False, verbose=False):
 
 SHIM_HIP = os.path.join(HERE, "ref_shim_hip")
 LIB_DEV = os.path.join(OUT_DIR, "libref_raster_gfx950.so")
+LIB_DEV_FMA = os.path.join(OUT_DIR, "libref_raster_gfx950_fma.so")
 
 
-def build_device(force=False, verbose=False):
+def build_device(force=False, verbose=False, contract="off"):
     """The same reference sources compiled by hipcc for gfx950 (streamed through ONE whitespace rewrite: the reference
     spells its launches `kernel << <grid, block >> > (...)`, which nvcc accepts and clang does not -> `kernel<<<grid, block>>>(`) against
     oracle/ref_shim_hip/ (CUDA header names -> ROCm headers, cub -> hipCUB, the GLM subset with device qualifiers) plus
     ref_capi_hip.cpp.  Output: oracle/_ref/libref_raster_gfx950.so -- the reference's own kernels on the MI355X, used as a
-    device-side checker at full sizes and as the `reference_on_device` baseline of bench.py.  Returns the path or None."""
+    device-side checker at full sizes and as the `reference_on_device` baseline of bench.py.  Returns the path or None.
+
+    contract="fast": a second library, libref_raster_gfx950_fma.so, with the compiler's DEFAULT floating-point contraction
+    (hipcc -ffp-contract=fast; nvcc's default -fmad=true is the same choice, i.e. how the reference's own setup.py builds
+    it).  Only used to measure how far the reference moves under its own build flags (tests/test_gpu_ref_selfcal.py)."""
+    LIB_DEV = LIB_DEV_FMA if contract == "fast" else globals()["LIB_DEV"]
     if not available():
         return LIB_DEV if os.path.exists(LIB_DEV) else None
     deps = list(SOURCES) + [os.path.abspath(__file__)]
@@ -104,7 +110,7 @@ def build_device(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -ffp-contract=off like the host build: float32 in source operand order (with contraction the per-Gaussian records
     # differ in their last bits and ~0.1 % of the pixels of a 1080p view move by more than 1e-5)
-    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-w", "-I", SHIM_HIP,
+    flags = ["--offload-arch=gfx950", "-O3", "-ffp-contract=" + contract, "-std=c++17", "-fPIC", "-w", "-I", SHIM_HIP,
              "-I", os.path.join(RAST, "cuda_rasterizer"), "-I", KNN]
     objs = []
     procs = []
@@ -113,10 +119,10 @@ def build_device(force=False, verbose=False):
     tmp = []
     try:
         for src in SOURCES + [os.path.join(SHIM_HIP, "ref_capi_hip.cpp")]:
-            obj = os.path.join(OUT_DIR, "dev_" + os.path.basename(src) + ".o")
+            obj = os.path.join(OUT_DIR, f"dev_{contract}_" + os.path.basename(src) + ".o")
             text = open(src, encoding="utf-8", errors="replace").read()
             text = LAUNCH.sub(r"\1<<<\2>>>(", text)
-            scratch = os.path.join(OUT_DIR, "scratch_" + os.path.basename(src) + ".hip")
+            scratch = os.path.join(OUT_DIR, f"scratch_{contract}_" + os.path.basename(src) + ".hip")
             with open(scratch, "w") as f:
                 f.write(f'#line 1 "{src}"\n{text}')
             tmp.append(scratch)

@@ -12,18 +12,21 @@ import torch
 from . import build_ref
 
 _lib = None
+_libs = {}
 
 
-def available():
-    return build_ref.build_device() is not None and torch.cuda.is_available()
+def available(contract="off"):
+    return build_ref.build_device(contract=contract) is not None and torch.cuda.is_available()
 
 
-def lib():
+def lib(contract="off"):
+    """contract="off": IEEE operations in source order (the checker).  "fast": the compiler's default FMA contraction, i.e.
+    the reference as its own build produces it (build_ref.build_device)."""
     global _lib
-    if _lib is None:
-        path = build_ref.build_device()
+    if contract not in _libs:
+        path = build_ref.build_device(contract=contract)
         if path is None:
-            raise RuntimeError("oracle/_ref/libref_raster_gfx950.so is not built and /root/reference is not present")
+            raise RuntimeError(f"oracle/_ref gfx950 build (contract={contract}) is missing and /root/reference is not present")
         L = ctypes.CDLL(path)
         vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
         L.refdev_state_new.restype = vp
@@ -36,8 +39,10 @@ def lib():
                                       vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.refdev_sync.argtypes = []
         L.refdev_dist2.argtypes = [ci, vp, vp]
-        _lib = L
-    return _lib
+        _libs[contract] = L
+        if contract == "off":
+            _lib = L
+    return _libs[contract]
 
 
 def _p(t):
@@ -47,13 +52,13 @@ def _p(t):
 class Renderer:
     """One view at a time; keeps the reference's three scratch buffers between forward and backward."""
 
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, contract="off"):
+        self.L = lib(contract)
         self.state = self.L.refdev_state_new()
 
     def __del__(self):
-        if getattr(self, "state", None) and _lib is not None:
-            _lib.refdev_state_free(self.state)
+        if getattr(self, "state", None) and self.L is not None:
+            self.L.refdev_state_free(self.state)
             self.state = None
 
     def forward(self, bg, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D, view, proj, tanfovx, tanfovy,

@@ -42,10 +42,11 @@ def fake(monkeypatch):
     monkeypatch.setattr(luciddreamer_amd, "_C", f, raising=False)
     config.set_async(False)
     config.reset()
-    config.dropped_views = config.rerendered_views = 0
+    config.dropped_views = config.rerendered_views = config.recovered_views = 0
     yield f
     config._pending.clear()
-    config._override.clear()
+    config._stack().clear()
+    config._tls.exact = 0
     config.set_async(True)                     # the module default
     config._hwm.clear()
     config._seen.clear()
@@ -167,3 +168,43 @@ def test_check_every_samples_and_warm_calls_stay_exact(fake):
     assert fake.next == (base + 6) // 3 - base // 3                  # every third async forward posts a ticket
     fake.complete(*range(fake.next))
     config.drain()
+
+
+def test_recover_policy_marks_the_view_and_neither_warns_nor_counts_a_drop(fake):
+    """What parallel.ViewStreams runs under: the entry of an overflowed view carries True after the drain (the owner runs
+    the view again), nothing is warned about or counted as dropped, every view is checked whatever check_every says, and
+    force_exact() makes the re-run an exact-mode forward."""
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, headroom=1.0, warm_calls=1, check_every=4)
+    config.note_forward(means, rs, 1_000, None, 0)
+    cap = config.capacity_for(means, rs)
+    with config.overflow_policy("recover"):
+        assert not config.verifying(cap)
+        for h in (_header(900), _header(50_000, overflow=1), _header(950)):
+            config.note_forward(means, rs, -1, h, cap)
+    entries = list(config._pending)
+    assert len(entries) == 3 and all(e[3] is None for e in entries)           # check_every does not sample under "recover"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        config.drain()
+    assert [e[3] for e in entries] == [False, True, False] and not w and config.dropped_views == 0
+    assert config.capacity_for(means, rs) == 50_000 + 4096
+    with config.force_exact():
+        assert config.capacity_for(means, rs) == 0
+        with config.force_exact():
+            assert config.capacity_for(means, rs) == 0
+        assert config.capacity_for(means, rs) == 0
+    assert config.capacity_for(means, rs) != 0
+
+
+def test_policy_stack_is_per_thread_and_tolerates_an_unbalanced_exit(fake):
+    import threading
+    seen = {}
+    with config.overflow_policy("drop"):
+        t = threading.Thread(target=lambda: seen.setdefault("other", config.current_policy()))
+        t.start()
+        t.join()
+        assert config.current_policy() == "drop"
+    assert seen["other"] == "verify"                                 # another thread never sees this thread's override
+    config.overflow_policy("drop").__exit__(None, None, None)        # exit without enter: no IndexError, nothing popped
+    assert config.current_policy() == "verify"

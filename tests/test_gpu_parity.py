@@ -386,6 +386,64 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     assert np.abs(m1 - m2).max() <= 1e-5 * np.abs(m1).max()
 
 
+def test_view_pipeline_recovers_views_that_overflow_their_buffer(hip_device):
+    """a ViewStreams step must not lose a view.  The high-water mark is made too small for most views of the
+    path (as after a densification, or on a path whose first views are the cheap ones): those views overflow their binning
+    buffer, the device-side guard zeroes their gradients, and end_step() runs them again in exact mode -- the step's
+    gradients equal the exact-mode sum, `recovered` says how many views it took, nothing is counted as dropped."""
+    from depth_diff_gaussian_rasterization_min import GaussianRasterizationSettings, GaussianRasterizer
+    from luciddreamer_amd import config, parallel
+    P = 30_000
+    cloud = synthetic.make_cloud(P, "band", 4)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(320, 180, n_views=6)]
+    g = synthetic.upstream_grad(180, 320).to(hip_device)
+    bg = torch.zeros(3, device=hip_device)
+    rast = []
+    for c in cams:
+        tfx, tfy = hp.tan_fov(c)
+        rast.append(GaussianRasterizer(GaussianRasterizationSettings(
+            180, 320, tfx, tfy, bg, 1.0, c.world_view_transform, c.full_proj_transform, 3, c.camera_center, False, False)))
+
+    def run(starved):
+        leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
+        grads = parallel.FlatGrads(list(leaf.values()))
+        m2d = torch.zeros(P, 3, device=hip_device, requires_grad=True)
+        m2d.grad = torch.zeros_like(m2d)
+        config.reset()
+        config.set_async(True, headroom=1.0, warm_calls=1)
+        config.set_fused_grad_accumulation(True)
+        config.dropped_views = config.recovered_views = 0
+        try:
+            fwd = lambda r: r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"], shs=leaf["shs"],
+                              scales=leaf["scales"], rotations=leaf["rotations"])[0]
+            if starved:
+                with torch.no_grad():
+                    fwd(rast[0])                                      # warm call: the key is known ...
+                key = next(iter(config._hwm))
+                config._hwm[key] = 64                                 # ... and its mark far too small: 64 + 4096 instances
+            else:
+                config.set_async(False)
+            pipe = parallel.ViewStreams(hip_device, 2)
+            pipe.begin_step()
+            for r in rast:
+                pipe.run_view(lambda r=r: fwd(r), lambda col: col.backward(g))
+            recovered = pipe.end_step()
+            torch.cuda.synchronize()
+            assert config.current_policy() == "verify"                # the step's temporary policy is gone
+        finally:
+            config.set_fused_grad_accumulation(False)
+            config.reset()
+            config.set_async(True)
+        return grads.flat.cpu().numpy().copy(), m2d.grad.cpu().numpy().copy(), recovered
+
+    f_exact, m_exact, r0 = run(False)
+    f_rec, m_rec, r1 = run(True)
+    assert r0 == 0 and r1 >= 1 and config.dropped_views == 0, (r0, r1, config.dropped_views)
+    assert np.abs(f_exact).max() > 0
+    assert np.abs(f_exact - f_rec).max() <= 1e-5 * np.abs(f_exact).max()
+    assert np.abs(m_exact - m_rec).max() <= 1e-5 * np.abs(m_exact).max()
+
+
 @pytest.mark.parametrize("W,H", [(512, 512), (1920, 1080)])
 def test_backward_is_bit_repeatable(hip_device, W, H):
     """a deterministic backward is the default.  512x512 uses the 4-wave (quadrant) shape of the blend

@@ -1,5 +1,5 @@
-"""Both execution shapes of the blend backward kernel (render_bwd.hip: 2 waves per tile with two pixels per lane, or
-one 8x8 quadrant per wave) against the CPU oracle on the same scenes.  The library picks the shape from the tile count
+"""The three execution shapes of the blend backward kernel (render_bwd.hip: 2 waves per tile with two pixels per lane,
+one 8x8 quadrant per wave, or one wave per tile with four pixels per lane) against the CPU oracle on the same scenes.  The library picks the shape from the tile count
 and reads LR_BLEND_QUAD_BWD once per process, so each shape runs in its own interpreter."""
 import os
 import subprocess
@@ -23,13 +23,14 @@ for (P, W, H, seed) in ((20000, 320, 200, 0), (3000, 333, 77, 1), (50000, 640, 3
     ref = hp.run_oracle(cloud, cam, 3, bg, g)
     hip = hp.run_hip(cloud, cam, 3, bg, dev, g)
     hp.compare_forward(hip, ref)
-    if seed == 0 or not ref["res"].stage()["fragile"].any():        # scene 0 is the smoke scene: always compared
-        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+    # every row within 1e-4 of its tensor's maximum; rows beyond (at most 8, at most 1e-3) must sit on a pixel the oracle flags
+    # as within float32 rounding of a discrete decision (helpers.compare_grads_by_row)
+    hp.compare_grads_by_row(hip, ref, P, max_outliers=8)
 print("SHAPE-OK")
 """
 
 
-@pytest.mark.parametrize("quad", ["0", "1"])
+@pytest.mark.parametrize("quad", ["0", "1", "2"])
 def test_blend_backward_shape_matches_oracle(hip_device, quad):
     env = dict(os.environ, LR_BLEND_QUAD_BWD=quad, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
@@ -52,10 +53,7 @@ def test_4k_image_more_tiles_than_partition_bins(hip_device):
     ref = hp.run_oracle(cloud, cam, 3, bg, g)
     hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
     hp.compare_forward(hip, ref, max_fragile=4e-4 * W * H)     # 8.3 M pixels, splats tens of pixels wide
-    if not ref["res"].stage()["fragile"].any():
-        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
-    else:
-        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"), rtol=1e-3)
+    hp.compare_grads_by_row(hip, ref, P, max_outliers=16)
     u = _unpack(_raw_forward(cloud, cam, 3, bg, hip_device), P, W, H)
     st = ref["res"].stage()
     rng, orng = u["ranges"].astype(np.int64), st["ranges"].astype(np.int64)

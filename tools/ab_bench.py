@@ -31,8 +31,11 @@ def main():
     ap.add_argument("--streams", type=int, default=3)
     ap.add_argument("--stages", default="render_bwd,render_fwd,preprocess,gauss_bwd")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--also", default="", help="other knobs held fixed during the run: name=value[,name=value]")
     a = ap.parse_args()
     from luciddreamer_amd import _lib
+    for kv in filter(None, a.also.split(",")):
+        _lib.tune_set(kv.split("=")[0], int(kv.split("=")[1]))
     values = [int(v) for v in a.values.split(",")]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
