@@ -186,6 +186,20 @@ class Workload:
                     batch.run(self.m2d_grad, reduce=False)
                     opt.step()
                 return step
+            if api == "views" and getattr(self.args, "exchange", "allreduce") == "sparse-rows":
+                # the same sum as the all-reduce; only the rows this rank's views touched travel in the reduce half
+                self.chunks = 1
+                self.batch = parallel.ChunkedViewStep(self.cams, [self.grad_color] * len(self.cams), named, self.degree,
+                                                      self.bg, self.capacity, n_streams=streams, chunks=1)
+                self.grads = self.batch.grads
+                batch = self.batch
+                self.exchange_info = []
+
+                def step():
+                    self.m2d_grad.zero_()
+                    batch.run(self.m2d_grad, reduce=False)
+                    self.exchange_info.append(parallel.sparse_rows_all_reduce(batch.grads.views))
+                return step
             if api == "views":
                 self.batch = parallel.ChunkedViewStep(self.cams, [self.grad_color] * len(self.cams), named, self.degree,
                                                       self.bg, self.capacity, n_streams=streams, chunks=chunks)
@@ -349,9 +363,11 @@ def main():
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
                     help="N > 1: strong = the workload's views per STEP shared by the ranks (BASELINE.json config 3; auto picks it), "
                          "weak = that many views per rank")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sharded-adam"],
-                    help="views API: allreduce = the metric's step (gradients all-reduced); sharded-adam = a training step, "
-                         "reduce-scatter + Adam on the rank's shard + all-gather of the parameters (extra work: not the metric)")
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sparse-rows", "sharded-adam"],
+                    help="views API: allreduce = the metric's step (gradients all-reduced, one dense bucket); sparse-rows = the same "
+                         "sum with the reduce-scatter half replaced by an all-to-all of the rows this rank's views touched "
+                         "(parallel.sparse_rows_all_reduce); sharded-adam = a training step, reduce-scatter + Adam on the rank's "
+                         "shard + all-gather of the parameters (extra work: not the metric)")
     ap.add_argument("--sustain-seconds", type=float, default=1.0,
                     help="after the K contract steps, time the same step for at least this long (reported as `sustained`)")
     ap.add_argument("--no-fused-accumulate", action="store_true",
@@ -378,6 +394,14 @@ def main():
     fused = not args.no_fused_accumulate
     value, ms_per_step, host_issue_ms, step_fn = run_leg(wl, args.api, args.exact, args.streams, args.steps, args.warmup, world, dev, fused)
     chunks = wl.chunks
+    exchange_bytes, exchange_detail = None, None
+    info = getattr(wl, "exchange_info", None)
+    if info:                                            # sparse-rows: measured per step (the last `steps` calls are the timed ones)
+        tail = info[-args.steps:]
+        mean = lambda k: int(sum(i[k] for i in tail) / len(tail))
+        exchange_bytes = mean("bytes_sent")
+        exchange_detail = {"rows_sent_per_step": mean("sent_rows"), "bytes_all_to_all": mean("bytes_all_to_all"),
+                           "bytes_all_gather": mean("bytes_all_gather"), "dense_ring_allreduce_bytes": mean("dense_equivalent_bytes")}
     # the contract's K steps are 0.1 s of GPU time at C3; the same step again for >= sustain-seconds as a cross-check
     sustained = None
     if args.sustain_seconds > 0:
@@ -448,7 +472,12 @@ def main():
                     "parallelism": (f"dp{world} (view i -> rank i mod {world}; gradients all-reduced "
                                     + ("once per step" if chunks == 1 else f"in {chunks} view groups, the first under the second")
                                     + ")") if world > 1 else "dp1",
-                    "allreduce_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
+                    # bytes every rank puts on its links per step (ring model: a dense fp32 all-reduce of L floats sends
+                    # 2 (n - 1) / n x 4 L; sparse-rows: measured rows x (4 + row bytes) + the all-gather half)
+                    "allreduce_bytes_per_step": (exchange_bytes if exchange_bytes is not None else
+                                                 int(2 * (world - 1) * bucket_bytes * chunks // world)) if world > 1 else 0,
+                    "allreduce_payload_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
+                    "exchange_detail": exchange_detail,
                     "dist_backend": backend, "dist_world_size": backend_world, "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
@@ -567,6 +596,24 @@ def run_cpu_baseline(wl):
                 key = "this_rasterizer" if be == "ours" else "reference_kernels_on_this_gpu"
                 out[key] = {"iter_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3),
                             "final_loss": round(float(res["loss"][-1]), 5)}
+            # the UNCHANGED loop again after ONE call, luciddreamer_amd.install(R): render_raw, the paired l1 / ssim pass,
+            # FusedAdam and the fused densification statistics are switched in underneath the reference's own names
+            import luciddreamer_amd
+            for _pass in range(2):
+                with ref_loop.stack("ours") as (R, dev):
+                    handle = luciddreamer_amd.install(R)
+                    try:
+                        gm = ref_loop.model_from_cloud(R, base, dev)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        res = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                    finally:
+                        luciddreamer_amd.uninstall(handle)
+            out["this_rasterizer_after_install"] = {
+                "iter_per_s": round(iters / dt, 1), "ms_per_iter": round(dt / iters * 1e3, 3), "final_loss": round(float(res["loss"][-1]), 5),
+                "what": "the same unchanged loop after luciddreamer_amd.install(reference modules): one call, no edits to the caller"}
             # the same iteration with the optional pieces of SURVEY.md section 8f switched in (one line
             # each in the reference's loop): render_raw (activations inside the kernels), the fused L1+DSSIM loss, the
             # fused Adam step and densification statistics -- same cloud, cameras, targets, view order and loss terms

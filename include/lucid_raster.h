@@ -343,6 +343,11 @@ int lr_l1_dssim_forward(int channels, int height, int width, const float* image,
                         float* out_loss3, void* workspace, size_t workspace_bytes, void* stream);
 int lr_l1_dssim_backward(int channels, int height, int width, const float* image, const float* gt, float lambda_dssim,
                          const float* upstream, const void* workspace, float* dL_dimage, void* stream);
+/* The same backward for a caller that composes l1 and ssim ITSELF (R/luciddreamer.py:301-303 calls l1_loss and ssim
+ * separately and weights them in Python): dL_dimage = w_l1[0] * d l1 / d image + w_ssim[0] * d ssim / d image, both weights
+ * device scalars (autograd's grad_outputs of the two means) -- no host synchronisation to read them. */
+int lr_l1_dssim_backward_weights(int channels, int height, int width, const float* image, const float* gt, const float* w_l1,
+                                 const float* w_ssim, const void* workspace, float* dL_dimage, void* stream);
 
 /* present[P] (1 byte each) = view-space z > 0.2.  Returns 0 or a negative LR_ERR_*. */
 int lr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -29,7 +29,7 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read", "lr_tune_set", "lr_request_early_header",
            "lr_take_early_ticket",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
-           "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward",
+           "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward", "lr_l1_dssim_backward_weights",
            "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats",
            "lr_views_train_workspace_bytes", "lr_views_train_accumulate", "lr_views_train_check")
 
@@ -120,6 +120,8 @@ def lib():
         L.lr_l1_dssim_forward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, ctypes.c_size_t, vp]
         L.lr_l1_dssim_backward.restype = ci
         L.lr_l1_dssim_backward.argtypes = [ci, ci, ci, vp, vp, cf, vp, vp, vp, vp]
+        L.lr_l1_dssim_backward_weights.restype = ci
+        L.lr_l1_dssim_backward_weights.argtypes = [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp]
         L.lr_select_workspace_bytes.restype = ctypes.c_size_t
         L.lr_select_workspace_bytes.argtypes = [ci]
         L.lr_select_rows.restype = ci

@@ -370,7 +370,7 @@ size_t loss_workspace_bytes(int C, int H, int W);
 void launch_loss_forward(int C, int H, int W, const float* img, const float* gt, float lambda, float* out3, char* ws,
                          hipStream_t s, bool defer_final = false);
 void launch_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda, const float* upstream,
-                          const char* ws, float* grad, hipStream_t s, float* final_out3 = nullptr);
+                          const char* ws, float* grad, hipStream_t s, float* final_out3 = nullptr, const float* w_ssim = nullptr);
 // bit positions of lr_backward's accumulate_mask (LR_ACC_* in lucid_raster.h)
 enum { ACC_MEAN2D = 0, ACC_CONIC = 1, ACC_OPACITY = 2, ACC_COLOR = 3, ACC_MEAN3D = 4, ACC_COV3D = 5, ACC_SH = 6,
        ACC_SCALE = 7, ACC_ROT = 8 };

@@ -233,7 +233,7 @@ k_loss_final(int n_blocks, double n_elems, float lambda, const float2* __restric
 
 __global__ void __launch_bounds__(LTHREADS)
 k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float inv_n, const float* __restrict__ upstream,
-           const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ D1,
+           const float* __restrict__ w_ssim, const float* __restrict__ img, const float* __restrict__ gt, const float* __restrict__ D1,
            const float* __restrict__ D2, const float* __restrict__ D3, float* __restrict__ grad,
            const float2* __restrict__ partials, int n_blocks, double n_elems, float* __restrict__ out3)
 {
@@ -341,7 +341,10 @@ k_ssim_bwd(int H, int W, int tiles_x, int tiles_y, Win win, float lambda, float 
         }
     }
     const float up = upstream != nullptr ? upstream[0] : 1.0f;
-    const float k_ssim = -lambda * inv_n * up, k_l1 = (1.0f - lambda) * inv_n * up;
+    // two-weight form (lr_l1_dssim_backward_weights): upstream = dL/d l1, w_ssim = dL/d ssim, both device scalars -- the
+    // caller composed the two means itself, with whatever weights
+    const float k_ssim = w_ssim != nullptr ? inv_n * w_ssim[0] : -lambda * inv_n * up;
+    const float k_l1 = w_ssim != nullptr ? inv_n * up : (1.0f - lambda) * inv_n * up;
     float* __restrict__ gradp = grad + plane;
 #pragma unroll
     for (int o = 0; o < 4; o++) {
@@ -381,7 +384,7 @@ void launch_loss_forward(int C, int H, int W, const float* img, const float* gt,
 }
 
 void launch_loss_backward(int C, int H, int W, const float* img, const float* gt, float lambda, const float* upstream,
-                          const char* ws, float* grad, hipStream_t s, float* final_out3)
+                          const char* ws, float* grad, hipStream_t s, float* final_out3, const float* w_ssim)
 {
     static const Win win = make_window();
     const size_t n = (size_t)C * H * W;
@@ -389,7 +392,7 @@ void launch_loss_backward(int C, int H, int W, const float* img, const float* gt
     const float* D = reinterpret_cast<const float*>(ws);
     const float2* partials = reinterpret_cast<const float2*>(ws + align_up(3 * n * sizeof(float)));
     hipLaunchKernelGGL(k_ssim_bwd, dim3((C * tx * ty + 7) / 8 * 8), dim3(LTHREADS), 0, s, H, W, tx, ty, win, lambda, (float)(1.0 / (double)n),
-                       upstream, img, gt, D, D + n, D + 2 * n, grad, partials, C * tx * ty, (double)n, final_out3);
+                       upstream, w_ssim, img, gt, D, D + n, D + 2 * n, grad, partials, C * tx * ty, (double)n, final_out3);
 }
 
 }  // namespace lr

@@ -69,3 +69,77 @@ def ssim(img1, img2, window_size=11, size_average=True):
     if window_size != 11 or not size_average:
         raise NotImplementedError("fused ssim supports window_size=11, size_average=True")
     return 1.0 - _L1DSSIM.apply(img1, img2, 1.0)
+
+
+class _L1SSIMPair(torch.autograd.Function):
+    """(l1, ssim) of one image pair from ONE forward pass, for callers that weight the two means themselves
+    (/root/reference/luciddreamer.py:301-303: `(1 - l) * l1_loss(image, gt) + l * (1 - ssim(image, gt))`); the backward takes
+    both grad_outputs as device scalars (lr_l1_dssim_backward_weights)."""
+
+    @staticmethod
+    def forward(ctx, image, gt):
+        if not image.is_cuda or not gt.is_cuda:
+            raise RuntimeError("luciddreamer_amd.loss: image and gt must be on a HIP device (no CPU path)")
+        if image.shape != gt.shape or image.dim() < 2 or image.dtype != torch.float32 or gt.dtype != torch.float32:
+            raise RuntimeError("image and gt must be float32 tensors of the same [..., H, W] shape")
+        x, g = image.contiguous(), gt.contiguous()
+        H, W = int(x.shape[-2]), int(x.shape[-1])
+        C = x.numel() // (H * W)
+        L = _lib.lib()
+        dev = x.device
+        out3 = torch.empty((3,), dtype=torch.float32, device=dev)
+        ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), 0.0, out3.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.raise_for(rc, "l1 / ssim pair")
+        ctx.save_for_backward(x, g, ws)
+        ctx.dims, ctx.in_shape = (C, H, W), image.shape
+        return out3[1], out3[2]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim):
+        x, g, ws = ctx.saved_tensors
+        C, H, W = ctx.dims
+        L = _lib.lib()
+        dev = x.device
+        as_w = lambda t: (torch.zeros(1, device=dev) if t is None else t.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous())
+        w1, w2 = as_w(g_l1), as_w(g_ssim)
+        grad = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            rc = L.lr_l1_dssim_backward_weights(C, H, W, x.data_ptr(), g.data_ptr(), w1.data_ptr(), w2.data_ptr(), ws.data_ptr(),
+                                                grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.raise_for(rc, "l1 / ssim pair backward")
+        return grad.view(ctx.in_shape), None
+
+
+class PairedLoss:
+    """`l1_loss` and `ssim` with the reference's signatures that share ONE kernel pass when they are called, in either order,
+    on the same (image, gt) tensors -- which is what the training loop does.  luciddreamer_amd.install() puts a pair of these
+    in place of utils/loss.py's functions.  A call with other tensors (or ssim with another window) computes on its own."""
+
+    def __init__(self):
+        self._key, self._pair = None, None
+
+    def _get(self, a, b):
+        key = (id(a), id(b), a._version, b._version, a.data_ptr(), b.data_ptr())
+        if self._key == key and self._pair is not None:
+            pair, self._key, self._pair = self._pair, None, None       # second of the two calls: hand out and forget
+            return pair
+        pair = _L1SSIMPair.apply(a, b)
+        self._key, self._pair = key, pair
+        return pair
+
+    def l1_loss(self, network_output, gt):
+        # only what the loop pairs with ssim goes through the shared pass: an RGB image against its target.  Anything else
+        # (a depth map, a vector) is the reference's own expression, utils/loss.py:18-19
+        if network_output.shape != gt.shape or network_output.dim() != 3 or network_output.shape[0] != 3 or not network_output.is_cuda:
+            return torch.abs(network_output - gt).mean()
+        return self._get(network_output, gt)[0]
+
+    def ssim(self, img1, img2, window_size=11, size_average=True):
+        if window_size != 11 or not size_average:
+            raise NotImplementedError("fused ssim supports window_size=11, size_average=True")
+        return self._get(img1, img2)[1]

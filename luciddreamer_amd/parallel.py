@@ -168,7 +168,8 @@ class ShardedAdam:
 
     params: the tensors in FlatGrads order; grads: their FlatGrads built with multiple_of = 4 x world_size (use
     ShardedAdam.make_buckets); lrs: one learning rate per tensor (mutable: `opt.lrs[i] = ...` follows a schedule).
-    The parameter count must not change between steps (after densification: build new buckets and a new ShardedAdam)."""
+    The parameter count must not change between steps; after densification `resized()` builds the optimizer of the new
+    parameter set and carries the moments of the surviving Gaussians over (as the reference's optimizer surgery does)."""
 
     def __init__(self, params: Sequence[torch.Tensor], grads: FlatGrads, lrs: Sequence[float], betas=(0.9, 0.999),
                  eps: float = 1e-15, adam_fn: Optional[Callable] = None):
@@ -197,6 +198,82 @@ class ShardedAdam:
     @staticmethod
     def make_buckets(params: Sequence[torch.Tensor]) -> FlatGrads:
         return FlatGrads(params, multiple_of=4 * world_size())
+
+    # ---- the moments outlive a change of the parameter count -------------------------------------------------------
+    def _full_moments(self):
+        """Both moment buffers in the (old) flat layout on every rank: two all-gathers of the shards."""
+        L = self.shard * self.world
+        full = []
+        for shard in (self.exp_avg, self.exp_avg_sq):
+            if self.world > 1:
+                out = torch.empty(L, dtype=torch.float32, device=shard.device)
+                dist.all_gather_into_tensor(out, shard)
+            else:
+                out = shard
+            full.append(out)
+        return full
+
+    @torch.no_grad()
+    def resized(self, new_params: Sequence[torch.Tensor], keep_mask: torch.Tensor, lrs: Optional[Sequence[float]] = None):
+        """After densify_and_prune changed the number of Gaussians: a new ShardedAdam over `new_params` (same tensors in the
+        same order, each with rows = keep_mask.sum() + appended rows) whose moments are those of the SURVIVING rows --
+        what the reference's _prune_optimizer / cat_tensors_to_optimizer do (scene/gaussian_model.py:273-326): pruned rows
+        lose their moments, appended rows start at zero, everything else is kept, and the step count carries on.
+        keep_mask: bool [P_old], True = the old row survives (in order) at the front of every new tensor.
+        Collective: two all-gathers of the old moment shards (the flat-index shards of the old and the new layout do not
+        line up), once per densification."""
+        keep_mask = keep_mask.reshape(-1).bool()
+        P_old = int(keep_mask.shape[0])
+        old_segments = list(self.grads.segments)
+        m_full, v_full = self._full_moments()
+        grads = ShardedAdam.make_buckets(new_params)
+        opt = ShardedAdam(new_params, grads, self.lrs if lrs is None else lrs, betas=self.betas, eps=self.eps, adam_fn=self.adam_fn)
+        opt.step_count = self.step_count
+        kept = int(keep_mask.sum())
+        for full_old, new_shard in ((m_full, opt.exp_avg), (v_full, opt.exp_avg_sq)):
+            new_full = torch.zeros(grads.flat.numel(), dtype=torch.float32, device=full_old.device)
+            for (off_o, n_o), (off_n, n_n), p in zip(old_segments, grads.segments, new_params):
+                if n_o % P_old != 0:
+                    raise ValueError("every tensor must have one row per Gaussian")
+                row = n_o // P_old
+                if p.numel() % row != 0 or p.numel() // row < kept:
+                    raise ValueError("new tensor does not hold the surviving rows")
+                rows_old = full_old[off_o:off_o + n_o].view(P_old, row)
+                new_full[off_n:off_n + kept * row].view(kept, row).copy_(rows_old[keep_mask])
+            new_shard.copy_(new_full[opt.lo:opt.hi])
+        return opt
+
+    def state_dict(self):
+        """This rank's shard of the optimizer state (moments of flat indices [lo, hi)) plus what is replicated."""
+        return {"step": self.step_count, "lo": self.lo, "hi": self.hi, "world": self.world, "lrs": list(self.lrs),
+                "betas": tuple(self.betas), "eps": self.eps, "exp_avg": self.exp_avg.detach().clone(),
+                "exp_avg_sq": self.exp_avg_sq.detach().clone()}
+
+    def load_state_dict(self, state):
+        if (state["lo"], state["hi"], state["world"]) != (self.lo, self.hi, self.world):
+            raise ValueError("ShardedAdam.load_state_dict: the state was saved for another shard / world size "
+                             "(use full_state_dict / load_full_state_dict to move between them)")
+        self.step_count, self.lrs = int(state["step"]), [float(x) for x in state["lrs"]]
+        self.betas, self.eps = tuple(state["betas"]), float(state["eps"])
+        self.exp_avg.copy_(state["exp_avg"])
+        self.exp_avg_sq.copy_(state["exp_avg_sq"])
+
+    def full_state_dict(self):
+        """The whole state on every rank (two all-gathers), independent of the world size it was trained with."""
+        m, v = self._full_moments()
+        return {"step": self.step_count, "lrs": list(self.lrs), "betas": tuple(self.betas), "eps": self.eps,
+                "segments": list(self.grads.segments), "exp_avg": m.detach().clone(), "exp_avg_sq": v.detach().clone()}
+
+    def load_full_state_dict(self, state):
+        if [n for _, n in state["segments"]] != [n for _, n in self.grads.segments]:
+            raise ValueError("ShardedAdam.load_full_state_dict: tensor sizes differ")
+        self.step_count, self.lrs = int(state["step"]), [float(x) for x in state["lrs"]]
+        self.betas, self.eps = tuple(state["betas"]), float(state["eps"])
+        for full, shard in ((state["exp_avg"], self.exp_avg), (state["exp_avg_sq"], self.exp_avg_sq)):
+            mine = torch.zeros(self.shard * self.world, dtype=torch.float32, device=shard.device)
+            for (off_s, n), (off_n, _) in zip(state["segments"], self.grads.segments):     # paddings may differ with the world size
+                mine[off_n:off_n + n].copy_(full[off_s:off_s + n])
+            shard.copy_(mine[self.lo:self.hi])
 
     @torch.no_grad()
     def step(self):
@@ -295,6 +372,108 @@ def all_reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torc
     dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM)
     dist.all_reduce(denom, op=dist.ReduceOp.SUM)
     dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX)
+
+
+def densify_and_prune_synchronised(model, max_grad, min_opacity, extent, max_screen_size, seed: int):
+    """densify_and_prune of a data-parallel run: the statistics every rank accumulated over ITS views are
+    reduced first -- xyz_gradient_accum and denom SUM, max_radii2D MAX, what one process would have accumulated over all
+    views (R/scene/gaussian_model.py:405-407, R/luciddreamer.py:310-311) -- and densify_and_split's torch.normal samples
+    (:359-361) are drawn from generators every rank seeds identically for the duration of the call, so all replicas
+    clone, split and prune the same Gaussians into bit-identical parameter sets.  `seed` must be the same on every rank
+    (e.g. the iteration number).  Works with the reference's GaussianModel and with luciddreamer_amd.densify's methods."""
+    all_reduce_densification_stats(model.xyz_gradient_accum, model.denom, model.max_radii2D)
+    dev = model.get_xyz.device
+    with torch.random.fork_rng(devices=[dev] if dev.type == "cuda" else []):
+        torch.manual_seed(int(seed))                     # host and every device generator
+        model.densify_and_prune(max_grad, min_opacity, extent, max_screen_size)
+
+
+def ring_allreduce_bytes(n_floats: int, world: Optional[int] = None) -> int:
+    """Bytes every rank puts on its links for one dense fp32 all-reduce of n_floats (reduce-scatter + all-gather halves)."""
+    world = world_size() if world is None else world
+    return 0 if world <= 1 else int(2 * (world - 1) * n_floats * 4 // world)
+
+
+def _all_to_all(out: torch.Tensor, inp: torch.Tensor, out_splits=None, in_splits=None):
+    """dist.all_to_all_single; over gloo with device tensors (several ranks sharing one GPU: LR_DIST_BACKEND=gloo, debugging
+    only) the exchange is staged through the host -- gloo's all-to-all takes host tensors only."""
+    if inp.is_cuda and dist.get_backend() == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits)
+
+
+@torch.no_grad()
+def sparse_rows_all_reduce(views: Sequence[torch.Tensor], touched: Optional[torch.Tensor] = None) -> dict:
+    """All-reduce(SUM) of per-Gaussian gradient tensors whose LOCAL contribution is sparse in the rows.
+
+    A rank's views of a step touch a small part of the scene (C3: 4 views of a rotate360 path see ~9 % of the Gaussians
+    each), so the gradient it has accumulated is zero in most rows, while the SUM over all ranks is dense.  The dense
+    all-reduce is a reduce-scatter followed by an all-gather; here the reduce-scatter half is replaced:
+
+      rows are owned in contiguous blocks (rank r: rows [r P / n, (r + 1) P / n) of EVERY tensor);
+      every rank sends each row it touched -- index + all its floats, 4 + 236 B at SH degree 3 -- to the row's owner
+      (one all-to-all of indices, one of payloads; the counts go first);
+      the owner adds what it received to its own rows, source by source in rank order (indices are unique within a source:
+      no atomics, bit-repeatable);
+      the owners' blocks are all-gathered (in place when n divides P, else one broadcast per owner).
+
+    Every rank ends with the owners' bytes, so replicas stay bit-identical; the sum differs from the ring all-reduce's only
+    in association.  views: tensors [P, ...] (e.g. FlatGrads.views), modified in place.  touched: bool [P], rows with a
+    non-zero local contribution (default: computed here, one pass over the tensors).  Returns the bytes this rank sent."""
+    n, r = world_size(), get_rank()
+    P = int(views[0].shape[0])
+    rows = [v.view(P, -1) for v in views]
+    K = sum(x.shape[1] for x in rows)
+    if n == 1:
+        return {"sent_rows": 0, "bytes_sent": 0, "dense_equivalent_bytes": 0}
+    dev = rows[0].device
+    if touched is None:
+        touched = torch.zeros(P, dtype=torch.bool, device=dev)
+        for x in rows:
+            touched |= (x != 0).any(dim=1)
+    bounds = [i * P // n for i in range(n + 1)]
+    idx = touched.nonzero().view(-1)                                      # ascending
+    cuts = torch.searchsorted(idx, torch.tensor(bounds, device=dev, dtype=idx.dtype)).tolist()     # the step's one host read
+    send_counts = [0 if d == r else cuts[d + 1] - cuts[d] for d in range(n)]
+    sel = torch.cat([idx[cuts[d]:cuts[d + 1]] for d in range(n) if d != r]) if n > 1 else idx[:0]
+    payload = torch.cat([x[sel] for x in rows], dim=1) if sel.numel() else torch.zeros((0, K), dtype=torch.float32, device=dev)
+    cnt_in = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+    cnt_out = torch.zeros(n, dtype=torch.int64, device=dev)
+    _all_to_all(cnt_out, cnt_in)
+    recv_counts = cnt_out.tolist()
+    n_recv = sum(recv_counts)
+    idx_recv = torch.zeros(n_recv, dtype=torch.int32, device=dev)
+    _all_to_all(idx_recv, sel.to(torch.int32), recv_counts, send_counts)
+    pay_recv = torch.zeros((n_recv, K), dtype=torch.float32, device=dev)
+    _all_to_all(pay_recv, payload.contiguous(), recv_counts, send_counts)
+    off = 0
+    for src in range(n):                                                  # fixed order over the sources
+        c = recv_counts[src]
+        if c:
+            ii = idx_recv[off:off + c].long()
+            col = 0
+            for x in rows:
+                w = x.shape[1]
+                x.index_add_(0, ii, pay_recv[off:off + c, col:col + w])
+                col += w
+            off += c
+    lo, hi = bounds[r], bounds[r + 1]
+    if P % n == 0:
+        for x in rows:
+            dist.all_gather_into_tensor(x.view(-1), x[lo:hi].reshape(-1))   # in place: this rank's block IS slice r of the output
+    else:
+        for x in rows:
+            for o in range(n):
+                dist.broadcast(x[bounds[o]:bounds[o + 1]], src=o)
+    # bytes THIS rank puts on its links: its touched rows to their owners, then (ring all-gather) n - 1 blocks of P K / n floats
+    sent_rows = int(sel.numel())
+    a2a = sent_rows * (K * 4 + 4)
+    gather = (n - 1) * ((P + n - 1) // n) * K * 4
+    return {"sent_rows": sent_rows, "bytes_all_to_all": a2a, "bytes_all_gather": gather, "bytes_sent": a2a + gather,
+            "dense_equivalent_bytes": ring_allreduce_bytes(P * K, n)}
 
 
 class ViewStreams:

@@ -48,6 +48,22 @@ def sharded_main(out):
         torch.distributed.destroy_process_group()
 
 
+def sparse_main(out):
+    """The metric's step with the reduce half of the exchange as an all-to-all of the touched rows."""
+    rank, world, dev = parallel.init_distributed()
+    step, m2d = build(dev, 8, world, rank, 1)
+    infos = []
+    for _ in range(2):
+        step.run(m2d, reduce=False)
+        infos.append(parallel.sparse_rows_all_reduce(step.grads.views))
+    step.check()
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({"flat": step.grads.flat.cpu(), "world": world, "info": infos[-1]}, out)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     out = sys.argv[1]
     rank, world, dev = parallel.init_distributed()
@@ -67,5 +83,7 @@ def main():
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[2] == "sharded":
         sharded_main(sys.argv[1])
+    elif len(sys.argv) > 2 and sys.argv[2] == "sparse":
+        sparse_main(sys.argv[1])
     else:
         main()

@@ -1,0 +1,88 @@
+"""CPU: the mechanics of luciddreamer_amd.install() / uninstall() -- what is replaced where, re-binding of names a caller
+imported before the call, fall-through to the originals for calls the fused pieces do not cover, restoration.  The fused
+pieces themselves run on the GPU (tests/test_gpu_reference_stack.py::test_install_switches_the_unchanged_loop_onto_the_fused_pieces)."""
+import sys
+import types
+
+import torch
+
+import luciddreamer_amd
+from luciddreamer_amd import dropin
+
+
+def _fake_reference():
+    gr = types.ModuleType("fake_gaussian_renderer")
+    calls = []
+
+    def render(viewpoint_camera, pc, opt, bg_color, scaling_modifier=1.0, override_color=None, render_only=False):
+        calls.append("render")
+        return {"render": torch.zeros(3, 4, 4)}
+    gr.render = render
+    ls = types.ModuleType("fake_loss")
+    ls.l1_loss = lambda a, b: torch.abs(a - b).mean()
+    ls.ssim = lambda a, b, window_size=11, size_average=True: torch.tensor(1.0)
+
+    class GaussianModel:
+        def training_setup(self, args):
+            self.optimizer = torch.optim.Adam([{"params": [torch.nn.Parameter(torch.zeros(3))], "lr": 0.1, "name": "xyz"}],
+                                              lr=0.0, eps=1e-15)
+
+        def add_densification_stats(self, vsp, flt):
+            calls.append("stats")
+
+        def densify_and_prune(self, *a):
+            calls.append("densify")
+    gm = types.ModuleType("fake_gaussian_model")
+    gm.GaussianModel = GaussianModel
+    caller = types.ModuleType("fake_luciddreamer")            # `from gaussian_renderer import render` etc., done BEFORE install()
+    caller.render, caller.l1_loss, caller.ssim = gr.render, ls.l1_loss, ls.ssim
+    for m in (gr, ls, gm, caller):
+        sys.modules[m.__name__] = m
+    return gr, ls, gm, caller, calls
+
+
+def test_install_replaces_rebinds_falls_through_and_uninstall_restores():
+    gr, ls, gm, caller, calls = _fake_reference()
+    try:
+        orig = (gr.render, ls.l1_loss, ls.ssim, gm.GaussianModel.training_setup, gm.GaussianModel.add_densification_stats,
+                gm.GaussianModel.densify_and_prune)
+        h = luciddreamer_amd.install(gr, ls, gm)
+        assert gr.render is not orig[0] and caller.render is gr.render               # re-bound in the module that imported it by name
+        assert caller.l1_loss is ls.l1_loss and caller.ssim is ls.ssim and ls.l1_loss is not orig[1]
+        assert gm.GaussianModel.densify_and_prune is not orig[5] and hasattr(gm.GaussianModel, "save_ply")
+        # a call the fused render does not cover (CPU tensors, no stored parameters) goes to the original
+        pc = types.SimpleNamespace()
+        opt = types.SimpleNamespace(compute_cov3D_python=False, convert_SHs_python=False, debug=False)
+        assert "render" in gr.render(None, pc, opt, torch.zeros(3)) and calls == ["render"]
+        # l1 of something that is not an RGB image on the device: the reference's own expression
+        a, b = torch.rand(1, 8, 8), torch.rand(1, 8, 8)
+        assert torch.equal(ls.l1_loss(a, b), torch.abs(a - b).mean())
+        # Adam: parameters on the host -> the reference's optimizer is kept (FusedAdam has no CPU path)
+        m = gm.GaussianModel()
+        m.training_setup(None)
+        assert type(m.optimizer) is torch.optim.Adam
+        # statistics without the radii the fused render attaches -> the original method
+        m.add_densification_stats(types.SimpleNamespace(grad=None), torch.zeros(3, dtype=torch.bool))
+        assert calls[-1] == "stats"
+        luciddreamer_amd.uninstall(h)
+        now = (gr.render, ls.l1_loss, ls.ssim, gm.GaussianModel.training_setup, gm.GaussianModel.add_densification_stats,
+               gm.GaussianModel.densify_and_prune)
+        assert all(x is y for x, y in zip(orig, now)) and caller.render is orig[0] and caller.ssim is orig[2]
+        assert not hasattr(gm.GaussianModel, "save_ply")
+    finally:
+        for m in (gr, ls, gm, caller):
+            sys.modules.pop(m.__name__, None)
+
+
+def test_install_takes_a_namespace_and_switches_individually():
+    gr, ls, gm, caller, _ = _fake_reference()
+    try:
+        ns = types.SimpleNamespace(gaussian_renderer=gr, loss=ls, gaussian_model=gm)
+        orig_render, orig_l1 = gr.render, ls.l1_loss
+        h = dropin.install(ns, losses=False, densify=False)
+        assert gr.render is not orig_render and ls.l1_loss is orig_l1 and not hasattr(gm.GaussianModel, "save_ply")
+        dropin.uninstall(h)
+        assert gr.render is orig_render
+    finally:
+        for m in (gr, ls, gm, caller):
+            sys.modules.pop(m.__name__, None)

@@ -38,6 +38,26 @@ def test_two_ranks_equal_one_rank_on_the_flat_gradient_bucket(hip_device, tmp_pa
     assert np.abs(a - want).max() <= 2e-5 * np.abs(want).max()       # same sum, different association across ranks / chunks
 
 
+def test_sparse_rows_exchange_two_ranks_equal_one_rank(hip_device, tmp_path):
+    """--exchange sparse-rows on the real kernels: the rows each rank's 4 views touched go to their owners (all-to-all), the
+    owners' blocks are all-gathered; the bucket must equal one rank's sum over all 8 views, and the rows sent must be a
+    fraction of the scene."""
+    from tests import dist_gpu_worker as W
+    step, m2d = W.build(hip_device, 8, 1, 0, 1)
+    step.run(m2d)
+    step.check()
+    want = step.grads.flat.cpu().numpy()
+    out = str(tmp_path / "sparse.pt")
+    r = _torchrun(2, [os.path.join(ROOT, "tests", "dist_gpu_worker.py"), out, "sparse"], 29619)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    got = torch.load(out)
+    a = got["flat"].numpy()
+    assert got["world"] == 2 and a.shape == want.shape and np.abs(want).max() > 0
+    assert np.abs(a - want).max() <= 2e-5 * np.abs(want).max()
+    info = got["info"]
+    assert 0 < info["sent_rows"] < 15_000 and info["bytes_all_to_all"] < info["dense_equivalent_bytes"] // 2, info
+
+
 def test_sharded_adam_two_ranks_equal_one_rank_with_fused_adam(hip_device, tmp_path):
     """The strong-scaling training step on the real kernels: 8 views per step shared by 2 ranks, reduce-scatter of the
     flat bucket, lr_adam_step on each rank's shard, all-gather of the parameters -- against ONE rank rendering all 8 views
@@ -79,3 +99,21 @@ def test_bench_runs_under_two_ranks_and_reports_the_world_size(hip_device, scali
     cfg = line["config"]
     assert cfg["views_per_step"] == (4 if scaling == "strong" else 8) and cfg["views_per_rank_per_step"] == (2 if scaling == "strong" else 4)
     assert cfg["allreduce_bytes_per_step"] == cfg["grad_bucket_bytes"]          # few views per rank: one all-reduce per step
+
+
+def test_bench_reports_bytes_on_wire_for_both_exchanges(hip_device):
+    """config.allreduce_bytes_per_step for N > 1: the ring model for the dense all-reduce, measured rows for --exchange
+    sparse-rows."""
+    lines = {}
+    for ex, port in (("allreduce", 29621), ("sparse-rows", 29623)):
+        r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "100000",
+                          "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extras",
+                          "--exchange", ex], port)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        lines[ex] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["config"]
+    dense, sparse = lines["allreduce"], lines["sparse-rows"]
+    assert dense["allreduce_bytes_per_step"] == 2 * 1 * dense["allreduce_payload_bytes_per_step"] // 2
+    d = sparse["exchange_detail"]
+    assert sparse["exchange"] == "sparse-rows" and d["rows_sent_per_step"] > 0
+    assert sparse["allreduce_bytes_per_step"] == d["bytes_all_to_all"] + d["bytes_all_gather"]
+    assert d["bytes_all_to_all"] < d["dense_ring_allreduce_bytes"] // 2          # the reduce half shrank

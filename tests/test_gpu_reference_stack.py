@@ -70,6 +70,59 @@ def test_unchanged_reference_loop_small_with_densification(hip_device):
     assert b["loss"][-1] < b["loss"][0] and a["loss"][-1] < a["loss"][0]
 
 
+def test_install_switches_the_unchanged_loop_onto_the_fused_pieces(hip_device):
+    """luciddreamer_amd.install(R): the reference's loop (tests/ref_loop.py, nothing edited) over render_raw, the paired
+    l1 / ssim pass, FusedAdam, the fused densification statistics and the row-store densification -- against the same loop
+    with nothing installed.  Same cloud, cameras, targets and view order; 30 iterations without densification are the same
+    computation up to float rounding (loss curves within 1e-4, statistics within 1e-5); then a densify_and_prune must leave
+    the same number of Gaussians.  uninstall() puts every function back."""
+    import luciddreamer_amd
+    from luciddreamer_amd.optim import FusedAdam
+    W, H, iters, P = 256, 192, 30, 20_000
+    cams = cameras.lookaround_path(W, H, n_views=4, max_yaw_deg=10.0, max_pitch_deg=5.0)
+    base, hidden = _perturbed(P, 33, scale_mult=1.5)
+    targets, depths = _targets(hidden, cams)
+    order = [int(i) for i in np.random.default_rng(6).integers(0, 4, size=iters)]
+    out = {}
+    for mode in ("plain", "installed"):
+        with ref_loop.stack("ours") as (R, dev):
+            before = (R.gaussian_renderer.render, R.loss.l1_loss, R.loss.ssim, R.gaussian_model.GaussianModel.training_setup,
+                      R.gaussian_model.GaussianModel.add_densification_stats, R.gaussian_model.GaussianModel.densify_and_prune)
+            h = luciddreamer_amd.install(R) if mode == "installed" else None
+            try:
+                gm = ref_loop.model_from_cloud(R, base, dev)
+                res = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+                if h is not None:
+                    assert isinstance(gm.optimizer, FusedAdam) and R.gaussian_renderer.render is not before[0]
+                res["accum"] = gm.xyz_gradient_accum.detach().cpu().numpy().copy()
+                res["denom"] = gm.denom.detach().cpu().numpy().copy()
+                res["max_radii"] = gm.max_radii2D.detach().cpu().numpy().copy()
+                res["xyz"] = gm.get_xyz.detach().cpu().numpy().copy()
+                with torch.no_grad():
+                    gm.densify_and_prune(0.0002, 0.005, 3.0, None)
+                res["P_after"] = int(gm.get_xyz.shape[0])
+                # one more iteration on the re-sized model: optimizer state and parameters still line up
+                more = ref_loop.train(R, gm, dev, cams, order[:2], targets, depths, iters=2)
+                assert np.isfinite(more["loss"]).all()
+            finally:
+                if h is not None:
+                    luciddreamer_amd.uninstall(h)
+            after = (R.gaussian_renderer.render, R.loss.l1_loss, R.loss.ssim, R.gaussian_model.GaussianModel.training_setup,
+                     R.gaussian_model.GaussianModel.add_densification_stats, R.gaussian_model.GaussianModel.densify_and_prune)
+            assert all(x is y for x, y in zip(before, after)), "uninstall() must restore every function"
+            out[mode] = res
+    a, b = out["installed"], out["plain"]
+    rel = np.abs(a["loss"] - b["loss"]) / b["loss"]
+    print("install(): loss", b["loss"][0], "->", b["loss"][-1], "max relative loss distance", rel.max(), "P after densify",
+          a["P_after"], b["P_after"])
+    assert rel.max() < 1e-4 and b["loss"][-1] < b["loss"][0]
+    # the raw path applies exp / normalize inside the kernel: a radius (an integer ceil) may differ by one on a few Gaussians
+    assert np.array_equal(a["denom"], b["denom"])
+    assert np.abs(a["max_radii"] - b["max_radii"]).max() <= 1 and (a["max_radii"] != b["max_radii"]).mean() < 2e-3
+    assert np.abs(a["accum"] - b["accum"]).max() <= 1e-4 * np.abs(b["accum"]).max()
+    assert abs(a["P_after"] - b["P_after"]) <= max(3, 0.002 * b["P_after"])
+
+
 def test_c5_at_size_loss_curve_parity(hip_device):
     """BASELINE.json configs[4] at its stated size: 1 M Gaussians, 512x512, 200 Adam iterations with GSParams learning
     rates (R/arguments.py:19-34) towards fixed RGB + depth targets rendered from a perturbed copy.  Loss = the

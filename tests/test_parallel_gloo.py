@@ -198,3 +198,219 @@ def test_sharded_adam_single_rank_is_plain_adam():
         assert torch.allclose(p, q, rtol=0, atol=2e-6 * max(1.0, float(q.abs().max())))
     with pytest.raises(ValueError):
         parallel.ShardedAdam(params, parallel.FlatGrads(params, multiple_of=1) if grads.flat.numel() % 4 else grads, LRS[:2])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sparse-rows exchange: all-to-all of the touched rows to their owners + all-gather  ==  dense all-reduce
+# ---------------------------------------------------------------------------------------------------------------------
+def _sparse_local_grads(rank, P, it=0):
+    """Per-rank gradients that are zero outside the rows this rank's 'views' touched (different rows per rank, overlapping)."""
+    g = torch.Generator().manual_seed(77 + 13 * rank + 101 * it)
+    touched = torch.rand(P, generator=g) < 0.3
+    shapes = [(P, 3), (P, 3), (P, 4), (P, 1), (P, 9, 3)]
+    out = []
+    for sh in shapes:
+        t = torch.randn(sh, generator=g)
+        t[~touched] = 0.0
+        out.append(t.contiguous())
+    return out, touched
+
+
+def _sparse_worker(rank, world, port, out_dir, P):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo", device=torch.device("cpu"))
+    res = {}
+    for it, give_mask in enumerate((True, False)):
+        local, touched = _sparse_local_grads(rank, P, it)
+        dense = [t.clone() for t in local]
+        for t in dense:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        sparse = [t.clone() for t in local]
+        info = parallel.sparse_rows_all_reduce(sparse, touched if give_mask else None)
+        res[f"dense{it}"] = np.concatenate([t.numpy().ravel() for t in dense])
+        res[f"sparse{it}"] = np.concatenate([t.numpy().ravel() for t in sparse])
+        res[f"info{it}"] = np.array([info["sent_rows"], info["bytes_sent"], info["dense_equivalent_bytes"], int(touched.sum())])
+    np.savez(os.path.join(out_dir, f"sp{rank}.npz"), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("P", [64, 61])            # rows divisible by the world size (in-place all-gather) and not (broadcasts)
+def test_sparse_rows_exchange_equals_dense_all_reduce(tmp_path, P):
+    world = 2
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path), P), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "sp0.npz"), np.load(tmp_path / "sp1.npz")
+    for it in (0, 1):
+        assert np.array_equal(r0[f"sparse{it}"], r1[f"sparse{it}"]), "replicas diverged after the sparse exchange"
+        # two ranks: every sum has two operands, so the result is the dense all-reduce's bit for bit
+        assert np.array_equal(r0[f"sparse{it}"], r0[f"dense{it}"]) and np.abs(r0[f"dense{it}"]).max() > 0
+        for r in (r0, r1):
+            sent, nbytes, dense_bytes, touched = r[f"info{it}"]
+            K = 3 + 3 + 4 + 1 + 27
+            assert 0 < sent <= touched and nbytes == sent * (4 * K + 4) + ((P + 1) // 2) * K * 4 and dense_bytes == 2 * (P * K * 4) // 2
+
+
+def test_ring_allreduce_bytes_and_single_rank_sparse_is_a_no_op():
+    assert parallel.ring_allreduce_bytes(59_000_000, 8) == 2 * 7 * 59_000_000 * 4 // 8
+    assert parallel.ring_allreduce_bytes(10, 1) == 0
+    t = [torch.ones(5, 3)]
+    info = parallel.sparse_rows_all_reduce(t)
+    assert info["bytes_sent"] == 0 and torch.equal(t[0], torch.ones(5, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole data-parallel iteration with densification: render -> backward -> all-reduce -> reduced statistics -> seeded
+# densify_and_prune -> optimizer (ShardedAdam rebuilt for the new parameter count, moments carried over)
+# ---------------------------------------------------------------------------------------------------------------------
+class _TinyModel:
+    """The parts of GaussianModel the data-parallel densification touches (scene/gaussian_model.py:348-407), in plain
+    torch on the host: stored parameters, statistics, densify_and_prune with the reference's selection rules.  The last
+    keep mask and the number of appended rows are recorded for ShardedAdam.resized."""
+    NAMES = ("means3D", "scales", "rotations", "opacities", "shs")
+
+    def __init__(self, cloud):
+        self.t = {k: cloud[k].clone() for k in self.NAMES}
+        self.t["scales"] = torch.log(self.t["scales"])
+        self.reset_stats()
+        self.percent_dense = 0.01
+
+    def reset_stats(self):
+        P = self.P
+        self.xyz_gradient_accum, self.denom, self.max_radii2D = torch.zeros(P, 1), torch.zeros(P, 1), torch.zeros(P)
+
+    @property
+    def P(self):
+        return self.t["means3D"].shape[0]
+
+    @property
+    def get_xyz(self):
+        return self.t["means3D"]
+
+    def activated(self):
+        return [self.t["means3D"], torch.exp(self.t["scales"]), self.t["rotations"], self.t["opacities"], self.t["shs"]]
+
+    def densify_and_prune(self, max_grad, min_opacity, extent, max_screen_size):
+        grads = (self.xyz_gradient_accum / self.denom).nan_to_num(0.0).squeeze(1)
+        scale = torch.exp(self.t["scales"]).max(dim=1).values
+        clone = (grads >= max_grad) & (scale <= self.percent_dense * extent)
+        split = (grads >= max_grad) & (scale > self.percent_dense * extent)
+        new = {k: [v[clone]] for k, v in self.t.items()}
+        stds = torch.exp(self.t["scales"][split]).repeat(2, 1)
+        samples = torch.normal(mean=torch.zeros_like(stds), std=stds)              # the draw every rank must share
+        for k, v in self.t.items():
+            rep = v[split].repeat(2, *([1] * (v.dim() - 1)))
+            if k == "means3D":
+                rep = rep + samples
+            if k == "scales":
+                rep = torch.log(torch.exp(rep) / 1.6)
+            new[k].append(rep)
+        keep = ~split & ~(self.t["opacities"].squeeze(1) < min_opacity)
+        n_new = int(clone.sum()) + 2 * int(split.sum())
+        self.t = {k: torch.cat([v[keep]] + new[k]).contiguous() for k, v in self.t.items()}
+        self.last_keep, self.last_new = keep, n_new
+        self.reset_stats()
+
+
+def _dp_train(rank, world, iters=6, densify_at=(2, 4), sharded=True, exchange="allreduce"):
+    """`iters` data-parallel iterations of a tiny scene on the host (renders through the float64 torch restatement).
+    Returns the final parameters, P per iteration and the optimizer's step count."""
+    cloud, cams = _make_problem()
+    model = _TinyModel(cloud)
+    counts = []
+
+    def build(prev=None):
+        params = [torch.nn.Parameter(model.t[k].clone()) for k in _TinyModel.NAMES]
+        if sharded:
+            grads = parallel.ShardedAdam.make_buckets(params)
+            if prev is None:
+                opt = parallel.ShardedAdam(params, grads, LRS, adam_fn=_torch_adam_pieces)
+            else:
+                opt = prev.resized(params, model.last_keep)
+                grads = opt.grads
+        else:
+            grads = parallel.FlatGrads(params)
+            opt = None
+        return params, grads, opt
+    params, grads, opt = build()
+    plain = None if sharded else torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(params, LRS)], lr=0.0, eps=1e-15)
+    H = W = 32
+    g_up = synthetic.upstream_grad(H, W).double()
+    from oracle import torch_oracle
+    from tests import helpers as hp
+    for it in range(iters):
+        grads.zero_()
+        m3, sc_raw, rot, op, sh = params
+        for i in parallel.shard_views(len(cams), rank, world):
+            cam = cams[i]
+            tfx, tfy = hp.tan_fov(cam)
+            means2D = torch.zeros(m3.shape[0], 3, dtype=torch.float64, requires_grad=True)     # its gradient: the screen-space one
+            col, _, radii = torch_oracle.render(m3, op, cam.world_view_transform, cam.full_proj_transform, cam.camera_center,
+                                                tfx, tfy, H, W, torch.zeros(3), scales=torch.exp(sc_raw), rotations=rot, shs=sh,
+                                                degree=2, means2D=means2D)
+            ((col * g_up).sum().float() * (1.0 + 0.1 * i)).backward()
+            with torch.no_grad():                                      # the per-view statistics of R/luciddreamer.py:310-312
+                vis = radii > 0
+                model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
+                model.xyz_gradient_accum[vis] += torch.norm(means2D.grad[vis, :2].float(), dim=-1, keepdim=True)
+                model.denom[vis] += 1
+        if sharded:
+            opt.step()                                                 # reduce-scatter, Adam on the shard, all-gather
+        else:
+            if exchange == "sparse-rows":
+                parallel.sparse_rows_all_reduce(grads.views)
+            else:
+                grads.all_reduce()
+            plain.step()
+        with torch.no_grad():
+            for k, p in zip(_TinyModel.NAMES, params):
+                model.t[k] = p.detach().clone()
+        if it in densify_at:
+            parallel.densify_and_prune_synchronised(model, 1e-7, 0.005, 3.0, None, seed=1234 + it)
+            params, grads, opt = build(opt)
+            if not sharded:
+                old = plain
+                plain = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(params, LRS)], lr=0.0, eps=1e-15)
+                keep, n_new = model.last_keep, model.last_new
+                for gp_old, gp_new in zip(old.param_groups, plain.param_groups):      # the reference's optimizer surgery
+                    st = old.state[gp_old["params"][0]]
+                    z = lambda t: torch.cat([t[keep], torch.zeros((n_new,) + tuple(t.shape[1:]))])
+                    plain.state[gp_new["params"][0]] = {"step": st["step"].clone(), "exp_avg": z(st["exp_avg"]),
+                                                        "exp_avg_sq": z(st["exp_avg_sq"])}
+        counts.append(model.P)
+    flat = np.concatenate([model.t[k].numpy().ravel() for k in _TinyModel.NAMES])
+    return flat, counts, (opt.step_count if sharded else int(plain.state[plain.param_groups[0]["params"][0]]["step"]))
+
+
+def _dp_densify_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo", device=torch.device("cpu"))
+    torch.manual_seed(1000 + rank)                                     # different ambient RNG state per rank, on purpose
+    flat, counts, steps = _dp_train(rank, world, sharded=True)
+    flat2, counts2, _ = _dp_train(rank, world, sharded=False, exchange="sparse-rows")
+    np.savez(os.path.join(out_dir, f"dd{rank}.npz"), flat=flat, counts=np.array(counts), steps=steps, flat2=flat2,
+             counts2=np.array(counts2))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_iterations_with_densification_keep_replicas_identical(tmp_path):
+    """SURVEY.md 8e / VERDICT r3 item 4(i): two ranks run render -> backward -> exchange -> optimizer for six iterations with
+    a seeded, statistics-reduced densify_and_prune after iterations 2 and 4 (ShardedAdam rebuilt by resized(): moments of the
+    surviving Gaussians carried over).  The replicas must be bit-identical, and equal to ONE process doing all views with the
+    reference's optimizer surgery (torch.optim.Adam, moments of kept rows kept, new rows zero) up to float summation order."""
+    world = 2
+    mp.spawn(_dp_densify_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "dd0.npz"), np.load(tmp_path / "dd1.npz")
+    assert np.array_equal(r0["counts"], r1["counts"]) and np.array_equal(r0["flat"], r1["flat"]), "replicas diverged"
+    assert np.array_equal(r0["counts2"], r1["counts2"]) and np.array_equal(r0["flat2"], r1["flat2"]), "replicas diverged (sparse rows)"
+    assert len(set(r0["counts"].tolist())) > 1, "densification should change P"
+    assert int(r0["steps"]) == 6
+    torch.manual_seed(5)
+    ref_flat, ref_counts, ref_steps = _dp_train(0, 1, sharded=False)
+    assert ref_counts == r0["counts"].tolist() == r0["counts2"].tolist() and ref_steps == 6
+    for got in (r0["flat"], r0["flat2"]):
+        assert np.abs(got - ref_flat).max() <= 2e-5 * max(1.0, np.abs(ref_flat).max()), float(np.abs(got - ref_flat).max())
