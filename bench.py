@@ -223,10 +223,11 @@ class Workload:
             means2D.grad = self.m2d_grad.zero_() if fused else None
             pipe.begin_step()
             for r in self.rasterizers:
+                # grad_output: the views of a group share one pass of the autograd engine (parallel.ViewStreams.run_view)
                 pipe.run_view(
                     lambda r=r: r(means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
                                   shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0],
-                    lambda color: color.backward(grad_color))
+                    grad_output=grad_color)
             pipe.end_step()
             grads.all_reduce()
         return step
@@ -292,7 +293,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     # from the committed counter file of the same workload and build generation (tools/pmc_run.sh: separate passes for
     # FETCH_SIZE and WRITE_SIZE, both in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
     # reads on gfx950); `traffic_source` says which file.
-    traffic, valu, source = None, None, None
+    traffic, valu, source, traffic_ratios = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c3.json")
     if wl.name == "c3" and args.gaussians is None and os.path.exists(pmc_path):
         try:
@@ -308,31 +309,49 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
                 source = "committed PMC pass profiles/pmc_c3.json" + (f" ({allpmc['_collected']})" if "_collected" in allpmc else "")
             if "SQ_INSTS_VALU" in pmc:
-                # the blend kernels are VALU bound: wave-instructions per launch from the PMC
-                # pass over this launch's measured duration.  Reference rates (tools/valu_microbench.hip on MI355X):
-                # 880 G wave-instr/s for v_fma_f32, 440 G/s for v_pk_fma_f32, ~550 G/s for compares / selects / DPP adds
+                # the blend kernels are VALU bound: wave-instructions per launch from the PMC pass over
+                # this launch's measured duration, against the ARCHITECTURAL issue rate -- a wave64 VALU instruction occupies
+                # its SIMD-32 for 2 cycles (MI355X_MICROARCH.md): 1024 SIMDs x 2.4 GHz / 2 = 1228.8 G wave-instr/s.  Measured
+                # rates of single instructions (tools/valu_microbench.hip, 8 waves per SIMD): v_fma_f32 880 G/s (2.8 cycles),
+                # compares / selects / DPP adds ~550 G/s (4.4), v_exp / v_rcp / lane swaps ~270 G/s (9)
                 ginst = pmc["SQ_INSTS_VALU"] / dom_avg_s / 1e9
                 valu = {"wave_insts_per_launch": int(pmc["SQ_INSTS_VALU"]), "achieved_ginst_s": round(ginst, 1),
-                        "reference_ginst_s": {"v_fma_f32": 880.0, "v_pk_fma_f32": 440.0, "v_cmp_or_dpp": 550.0}}
+                        "architectural_peak_ginst_s": 1228.8, "frac_of_architectural_peak": round(ginst / 1228.8, 4),
+                        "measured_single_instruction_ginst_s": {"v_fma_f32": 880.0, "v_pk_fma_f32": 440.0, "v_cmp_or_dpp": 550.0,
+                                                                "v_exp_rcp_permlane_swap": 270.0}}
                 if "SQ_ACTIVE_INST_VALU" in pmc:
                     # cycles in which a SIMD's VALU was executing (counter is in units of 4 cycles, summed over the
                     # 1024 SIMDs) over the cycles of this launch at the 2.4 GHz peak clock
                     valu["valu_busy_frac"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / (1024 * dom_avg_s * 2.4e9), 4)
+                    valu["simd_cycles_per_instruction"] = round(pmc["SQ_ACTIVE_INST_VALU"] * 4.0 / pmc["SQ_INSTS_VALU"], 3)
+                if "effective_clock_ghz" in pmc:
+                    # GRBM_GUI_ACTIVE per XCD over the launch's wall time in the counter pass: the clock the kernel ran at
+                    valu["effective_clock_ghz"] = round(pmc["effective_clock_ghz"], 3)
+            # counter traffic against the algorithmic bytes, per kernel of the path (wasted re-reads show up here first)
+            ratios = {}
+            for st in single_kernel:
+                pk = next((v for k, v in allpmc.items() if isinstance(v, dict) and k.startswith("k_" + st)), None)
+                if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk:
+                    tb = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024
+                    ab = stage_bytes(st, P, V_mean, R_mean, N, T, K, M)
+                    ratios["k_" + st] = {"counter_bytes": int(tb), "algorithmic_bytes": int(ab), "ratio": round(tb / ab, 3)}
+            traffic_ratios = ratios or None
         except (OSError, ValueError):
             traffic = None
     moved_view_s = b_moved / max(sum(stages[k][0] for k in stages) / max(V * steps, 1) * 1e-3, 1e-12)
     return {
         "bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source, "valu_issue": valu,
+        "counter_vs_algorithmic_bytes": traffic_ratios,
         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
         "launches": dom_calls,
-        # whole path per view against the HBM peak: with the section-8d byte model as written (`contract`: it prices the
-        # reference's 300 B/Gaussian gradient zero-fill, which this design does not perform) and with the bytes this
-        # design has to move (`moved`)
-        "path_bytes_per_view": int(b_f + b_b),
-        "path_frac_contract": round((b_f + b_b) * per_rank_views_s / (HBM_PEAK_GBS * 1e9), 5),
+        # whole path per view against the HBM peak, with the bytes this design has to move
         "path_bytes_moved_per_view": int(b_moved),
         "path_frac_moved": round(b_moved * per_rank_views_s / (HBM_PEAK_GBS * 1e9), 5),
+        # footnote: the section-8d byte model as written also prices the reference's 300 B/Gaussian gradient zero-fill, which
+        # this design does not perform -- not work done, not a figure to quote
+        "footnote_contract_model": {"path_bytes_per_view": int(b_f + b_b),
+                                    "path_frac": round((b_f + b_b) * per_rank_views_s / (HBM_PEAK_GBS * 1e9), 5)},
         "stage_ms_per_view": {k: round(v[0] / max(V * steps, 1), 4) for k, v in stages.items()},
         "stage_sum_ms_per_view": round(sum(v[0] for v in stages.values()) / max(V * steps, 1), 4),
         "path_frac_moved_single_stream": round(moved_view_s / (HBM_PEAK_GBS * 1e9), 5),
@@ -458,7 +477,6 @@ def main():
             other[name] = {"workload": w2.label, "value": round(v, 1), "unit": "views/s", "steps": steps2,
                            "ms_per_step": round(ms, 3), "visible_mean": round(w2.V_mean, 1),
                            "num_rendered_mean": round(w2.R_mean, 1),
-                           "path_frac_contract": round((b_f + b_b) * v / (HBM_PEAK_GBS * 1e9), 5),
                            "path_frac_moved": round(b_m * v / (HBM_PEAK_GBS * 1e9), 5)}
             del w2
             torch.cuda.empty_cache()

@@ -384,6 +384,29 @@ int lr_header_poll(long long ticket, int block, unsigned int* out8);
  * "walk_own" (instances of a Gaussian the binning walks on its own lane), "hit_mask" (0: binning without preprocess's tile masks);
  * value -1 restores the library's own rule.  Results are identical up to float summation order whatever the setting.
  * Not part of the reference interface (it has no equivalent). */
+/* Ticket of the header of the LAST async-mode (binning_capacity > 0) lr_forward / lr_forward_raw on the calling thread, for
+ * lr_header_poll -- or -1 (no such forward yet, exact mode, P == 0).  Costs nothing: async-mode forwards leave their header in
+ * a ring of host-visible slots written by the scan kernel itself (no copy, no event; the poll spins on the slot's tag), which
+ * is what a caller that keeps several views in flight checks its views with (luciddreamer_amd/config.py).  The slot of a
+ * ticket is re-used after 4096 further forwards on the device. */
+long long lr_forward_ticket(void);
+/* A STEP of several views issued through the per-view entry points (what lr_views_accumulate is for callers that need the
+ * rendered image between forward and backward).  Between lr_step_begin and lr_step_end on a device, every accumulate-mode
+ * lr_backward / lr_backward_raw whose accumulate_mask covers mean2D, opacity, mean3D, scale and rotation (and that uses neither
+ * colors_precomp nor cov3D_precomp) adds those five rows into ONE interleaved 64-byte row per Gaussian owned by the library
+ * instead of five scattered 12-16 byte read-modify-writes; lr_step_end(stream) adds the touched rows into the five tensors
+ * the step's calls named (calls that name other tensors, or another P, accumulate directly as before).  The calls of a step
+ * must be ordered among themselves -- one stream, or lr_backward_wait_event chaining -- as accumulate-mode calls into shared
+ * tensors must be anyway; `stream` of lr_step_end must be ordered after all of them.  Returns 0 or a negative LR_ERR_*. */
+int lr_step_begin(void);
+int lr_step_end(void* stream);
+/* Accumulate-mode backward passes of different views on different streams add into the SAME gradient tensors and must not
+ * overlap there.  `event` (a hipEvent_t, or NULL) is consumed by the next lr_backward / lr_backward_raw on the calling thread:
+ * its stream waits for the event after the blend backward (which writes only the call's own scratch) and before the kernels
+ * that touch the outputs -- so a caller that records an event after each backward and passes it to the next one chains the
+ * accumulations while the blend backward of one view still overlaps the per-Gaussian backward of the previous one
+ * (csrc/torch_ext.cpp does this for the autograd operator; lr_views_accumulate does it internally). */
+void lr_backward_wait_event(void* event);
 int lr_tune_set(const char* name, int value);
 int lr_profile_enable(int on);
 const char* lr_profile_stage_name(int stage);

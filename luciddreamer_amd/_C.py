@@ -104,6 +104,12 @@ def take_early_ticket():
     return _C_ext.take_early_ticket()
 
 
+def last_forward_ticket():
+    """Ticket (for header_poll) of the last async-mode forward on this thread, from the library's forward log: costs nothing --
+    the scan kernel itself leaves the header in host-visible memory (lr_forward_ticket); -1 if there was none."""
+    return _C_ext.last_forward_ticket()
+
+
 def header_post(geomBuffer):
     """Non-blocking read-back of a forward's header on the current stream (lr_header_post); returns a ticket."""
     return _C_ext.header_post(geomBuffer)

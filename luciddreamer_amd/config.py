@@ -234,6 +234,8 @@ def note_forward(means3D, rs, num_rendered, geom, capacity):
     if policy != "recover" and _calls % _CHECK_EVERY:
         return
     from . import _C
-    # a 48-byte copy into pinned memory + an event, both owned by the library (lr_header_post): a few microseconds of host
-    # time per view.  Entry: [ticket, key, policy, overflowed (None until examined)]
-    _pending.append([_C.header_post(geom), key, policy, None])
+    # the forward left its header in the library's forward log (host-visible memory written by the scan kernel: no copy, no
+    # event, nothing enqueued); a library without one falls back to a 48-byte copy + event (lr_header_post).
+    # Entry: [ticket, key, policy, overflowed (None until examined)]
+    ticket = _C.last_forward_ticket() if hasattr(_C, "last_forward_ticket") else -1
+    _pending.append([ticket if ticket >= 0 else _C.header_post(geom), key, policy, None])

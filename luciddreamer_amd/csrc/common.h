@@ -270,8 +270,10 @@ void launch_preprocess(const ViewParams& vp, const float* means3D, const float* 
                        const float* colors_precomp, bool prefiltered, int* radii, GaussRec* rec,
                        uint8_t* clamped, uint32_t* tiles_touched, uint4* hitrec, uint32_t* depth_key,
                        GeomHeader* hdr, uint32_t binning_capacity, uint32_t* chunk_sums, bool sparse_view_hint, hipStream_t s);
-// zeroes the per-call part of the header and the chunk sums that k_preprocess adds into (chunk_sums == nullptr there: none)
-void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s);
+// chunk_sums: [ceil(P / SCAN_TILE)] x {emitting Gaussians, instances, rectangle areas, -} + one word (the prefilter trap), ZERO on
+// entry -- the library's own per-stream scratch (api.hip StreamScratch), cleared again by the first binning kernel once
+// k_compact_write has consumed it: no launch that only zeroes.
+inline size_t chunk_sum_words(int P) { return 4 * (((size_t)(P > 0 ? P : 1) + SCAN_TILE - 1) / SCAN_TILE) + 1; }
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,
                          hipStream_t s);
 
@@ -286,8 +288,11 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
 // instance counts (offsets, by rank: the per-Gaussian backward reads first slot and count from it); fills every count of the header: num_compact, num_rendered
 // (the reference's: sum of the tile-rectangle areas over all Gaussians), num_instances, num_sorted, overflow, bin_bound.
 // block_sums: per SCAN_TILE chunk {emitting Gaussians, instances, rectangle areas, -}, accumulated by k_preprocess.
+// capacity: the binning capacity of the call (0 = exact mode); log_slot: 12 host-visible words of the library's forward log or
+// nullptr -- the kernel leaves the header there behind `log_tag` (lr_header_poll on a log ticket spins on the tag).
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
-                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, hipStream_t s);
+                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
+                    uint32_t log_tag, hipStream_t s);
 // optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
 struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };
 // count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1
@@ -296,7 +301,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
                         const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
-                        long long bin_bound_hint, TileBinTimes* t, hipStream_t s);
+                        long long bin_bound_hint, TileBinTimes* t, uint32_t* clear_words, uint32_t n_clear, hipStream_t s);
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).

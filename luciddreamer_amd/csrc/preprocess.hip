@@ -161,7 +161,8 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
     __shared__ uint32_t s_list[PP_THREADS];
     __shared__ uint32_t s_wcnt[PP_WAVES];
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
+    // the prefilter trap lives behind the chunk sums, in the library's own scratch (zero between forwards: api.hip)
+    uint32_t* const trap = chunk_sums != nullptr ? chunk_sums + 4 * ((size_t)(vp.P + SCAN_TILE - 1) / SCAN_TILE) : &hdr->prefilter_trap;
     const float* __restrict__ V = vp.view;
     const float* __restrict__ Pm = vp.proj;
     {
@@ -170,7 +171,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
         const float vz1 = V[2] * means3D[3 * li] + V[6] * means3D[3 * li + 1] + V[10] * means3D[3 * li + 2] + V[14];
         const bool pass = in_range && !(vz1 <= 0.2f);
         if (in_range && !pass) {
-            if (prefiltered) hdr->prefilter_trap = 1;
+            if (prefiltered) *trap = 1;
             radii[gid] = 0; tiles_touched[gid] = 0;
             if (depth_key) depth_key[gid] = 0xFFFFFFFFu;
         }
@@ -316,7 +317,7 @@ k_preprocess(ViewParams vp, const float* __restrict__ means3D, const float* __re
 
     // this wave's share of the compaction's chunk sums (tilebin.hip k_compact_write): emitting Gaussians, instances,
     // the reference's rectangle areas.  Integer atomics: the result does not depend on their order.  All 128 Gaussians
-    // of the workgroup lie in one SCAN_TILE chunk (zeroed by k_forward_begin); dead lanes carry zeros.
+    // of the workgroup lie in one SCAN_TILE chunk (zero when the forward starts: api.hip StreamScratch); dead lanes carry zeros.
     if (chunk_sums != nullptr) {
         uint32_t inst = tiles_out, ref = area_ref;
 #pragma unroll
@@ -502,7 +503,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
     __shared__ uint32_t s_sum[3];
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     const int base = blockIdx.x * PL_POOL;
-    if (blockIdx.x == 0 && tid == 0) { hdr->capacity = binning_capacity; hdr->P = (uint32_t)vp.P; }   // rest of the header was zeroed
+    uint32_t* const trap = chunk_sums != nullptr ? chunk_sums + 4 * ((size_t)(vp.P + SCAN_TILE - 1) / SCAN_TILE) : &hdr->prefilter_trap;
     if (tid == 0) { s_nmid = 0u; s_sum[0] = 0u; s_sum[1] = 0u; s_sum[2] = 0u; }
     const float* __restrict__ V = vp.view;
 
@@ -516,7 +517,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
         const size_t li = in_range ? (size_t)gid : 0;
         const float vz1 = V[2] * means3D[3 * li] + V[6] * means3D[3 * li + 1] + V[10] * means3D[3 * li + 2] + V[14];
         pass[r] = in_range && !(vz1 <= 0.2f);
-        if (in_range && !pass[r] && prefiltered) hdr->prefilter_trap = 1;
+        if (in_range && !pass[r] && prefiltered) *trap = 1;
         s_radius[loc] = 0; s_tiles[loc] = 0u;
         m[r] = __ballot(pass[r]);
         if (l == 0) s_wcnt[r * PL_WAVES + w] = (uint32_t)__popcll(m[r]);
@@ -634,7 +635,7 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
     }
     // this workgroup's share of the compaction's chunk sums (tilebin.hip k_compact_write): emitting Gaussians, instances,
     // the reference's rectangle areas.  Integer atomics: the result does not depend on their order.  The pool lies in one
-    // SCAN_TILE chunk (zeroed by k_forward_begin).
+    // SCAN_TILE chunk (zero when the forward starts: api.hip StreamScratch).
     if (chunk_sums != nullptr) {
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
@@ -654,16 +655,6 @@ k_preprocess_pool(ViewParams vp, const float* __restrict__ means3D, const float*
         const int loc = r * PL_THREADS + tid, gid = base + loc;
         if (gid < vp.P) { radii[gid] = s_radius[loc]; tiles_touched[gid] = s_tiles[loc]; }
     }
-}
-
-// first launch of a forward: the header's per-call part and the compaction's chunk sums start at zero (one launch
-// instead of a memset per region)
-__global__ void __launch_bounds__(256)
-k_forward_begin(uint32_t* __restrict__ hdr_words, int n_hdr, uint32_t* __restrict__ chunk_sums, int n_sums)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n_hdr) hdr_words[i] = 0u;
-    if (i < n_sums) chunk_sums[i] = 0u;
 }
 
 __global__ void __launch_bounds__(256)
@@ -713,15 +704,6 @@ void launch_preprocess(const ViewParams& vp, const float* means3D, const float* 
         hipLaunchKernelGGL(k_preprocess<false>, grid, block, 0, s, vp, means3D, scales, rotations, opacities, shs,
                            cov3D_precomp, colors_precomp, prefiltered ? 1 : 0, radii, rec, clamped, tiles_touched,
                            hitrec, depth_key, hdr, binning_capacity, chunk_sums);
-}
-
-void launch_forward_begin(GeomHeader* hdr, uint4* chunk_sums, int P, hipStream_t s)
-{
-    const int n_hdr = (int)(offsetof(GeomHeader, sticky_overflow) / 4);
-    const int n_sums = 4 * ((P + SCAN_TILE - 1) / SCAN_TILE);
-    const int n = n_hdr > n_sums ? n_hdr : n_sums;
-    hipLaunchKernelGGL(k_forward_begin, dim3((n + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint32_t*>(hdr), n_hdr,
-                       reinterpret_cast<uint32_t*>(chunk_sums), n_sums);
 }
 
 void launch_mark_visible(int P, const float* means3D, const float* view, const float* proj, uint8_t* present,

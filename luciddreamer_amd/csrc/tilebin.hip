@@ -66,7 +66,8 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 // -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
-                uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, GeomHeader* hdr)
+                uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, GeomHeader* hdr, uint32_t capacity,
+                uint32_t* __restrict__ log_slot, uint32_t log_tag)
 {
     __shared__ uint32_t s_tmp[4];
     __shared__ uint32_t s_wc[4], s_wi[4];
@@ -114,15 +115,30 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
         }
     }
     if (last_block && threadIdx.x == SCAN_THREADS - 1) {
+        // EVERY per-call word of the header is written here (the buffer is the caller's, fresh memory per call: nothing is
+        // zeroed up front); the prefilter trap was left behind the chunk sums by k_preprocess
         const uint32_t total = run_i;
-        hdr->num_compact = run_c;
+        const bool over = (capacity != 0 && total > capacity);
+        const uint32_t trap = reinterpret_cast<const uint32_t*>(block_sums)[4 * (size_t)gridDim.x];
         hdr->num_rendered = ref_total;          // the reference's count (sum of rectangle areas)
-        hdr->num_instances = total;             // after exact tile culling: what is binned
-        const bool over = (hdr->capacity != 0 && total > hdr->capacity);
         hdr->overflow = over ? 1u : 0u;
+        hdr->prefilter_trap = trap;
+        hdr->capacity = capacity;
+        hdr->P = (uint32_t)P;
+        hdr->num_sorted = over ? capacity : total;
+        hdr->num_instances = total;             // after exact tile culling: what is binned
+        hdr->bin_bound = capacity != 0 ? capacity : total;   // what the binning buffer is laid out for
+        hdr->num_compact = run_c;
         if (over) hdr->sticky_overflow = 1u;
-        hdr->num_sorted = over ? hdr->capacity : total;
-        hdr->bin_bound = hdr->capacity != 0 ? hdr->capacity : total;   // what the binning buffer is laid out for
+        if (log_slot != nullptr) {
+            // the library's forward log (host-visible memory, api.hip ForwardLog): the header words first, the tag last,
+            // each with system scope -- the host spins on the tag instead of waiting for a copy and an event
+            const uint32_t w[9] = { ref_total, over ? 1u : 0u, trap, capacity, (uint32_t)P, over ? capacity : total, total,
+                                    capacity != 0 ? capacity : total, run_c };
+#pragma unroll
+            for (int i = 0; i < 9; i++) __hip_atomic_store(log_slot + 1 + i, w[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(log_slot, log_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -341,9 +357,12 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
        const uint32_t* __restrict__ offsets, const uint4* __restrict__ hitrec, const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
        uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
        uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ inst_gid,
-       unsigned long long* __restrict__ words)
+       unsigned long long* __restrict__ words, uint32_t* __restrict__ clear_words, uint32_t n_clear)
 {
     extern __shared__ uint32_t s_bin[];                  // [bins + bins / 16 + 1], indexed through bin_slot()
+    // the forward's chunk sums (library scratch) have been consumed by k_compact_write: zero for the next forward on this stream
+    if (MODE == 0 && blockIdx.x == 0)
+        for (uint32_t i = threadIdx.x; i < n_clear; i += PART_THREADS) clear_words[i] = 0u;
     const uint32_t V = hdr->num_compact;
     const int nb = part_active_blocks(V);
     const int b = (int)blockIdx.x;
@@ -681,18 +700,19 @@ PartPlan part_plan(int num_tiles)
 }
 
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
-                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, hipStream_t s)
+                    uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
+                    uint32_t log_tag, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
-                       offsets, hdr);
+                       offsets, hdr, capacity, log_slot, log_tag);
 }
 
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
                         const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
                         uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
-                        long long bin_bound_hint, TileBinTimes* t, hipStream_t s)
+                        long long bin_bound_hint, TileBinTimes* t, uint32_t* clear_words, uint32_t n_clear, hipStream_t s)
 {
     // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort up to 128 KB.  The attribute is
     // set once per DEVICE (a process may drive several; runtimes that keep it per device would otherwise refuse the
@@ -727,14 +747,14 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
-                       inst_gid, words);
+                       inst_gid, words, clear_words, n_clear);
     if (t) t->mark(1, s);
     hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
                        part_hist, bin_total);
     if (t) t->mark(2, s);
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
-                       inst_gid, words);
+                       inst_gid, words, nullptr, 0u);
     if (t) t->mark(3, s);
     const int groups4 = (pp.bins + 3) / 4;
     const int part_b = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;

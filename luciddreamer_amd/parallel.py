@@ -476,6 +476,37 @@ def sparse_rows_all_reduce(views: Sequence[torch.Tensor], touched: Optional[torc
             "dense_equivalent_bytes": ring_allreduce_bytes(P * K, n)}
 
 
+def _direct_backward(out: torch.Tensor, grad_output: torch.Tensor) -> bool:
+    """Backward of ONE rasterizer node without the autograd engine: `out` must be the image returned by the rasterizer op,
+    every differentiable input of the node a LEAF (its next function an AccumulateGrad, or none), and fused gradient
+    accumulation on, so that the node's kernels add into the leaves' .grad in place.  The node is called on the calling thread
+    and current stream (= the stream of its forward); a gradient it returns for a leaf it could not accumulate into (no .grad
+    yet, unsuitable layout) is added the way AccumulateGrad would.  Returns False -- nothing done -- when the shape of the
+    graph is anything else: the caller goes through the engine then.  Tensor hooks on the leaves are not run (as with fused
+    accumulation in general, config.set_fused_grad_accumulation)."""
+    from . import config
+    fn = out.grad_fn
+    if fn is None or not config.fused_grad_accumulation() or "Rasterize" not in type(fn).__name__ + fn.name():
+        return False
+    leaves = []
+    for nxt, _ in fn.next_functions:
+        if nxt is None:
+            leaves.append(None)
+        elif type(nxt).__name__ == "AccumulateGrad":
+            leaves.append(nxt.variable)
+        else:
+            return False
+    n_out = 4 if "RasterizeFn" in fn.name() else 3               # compiled node: (color, radii, depth, geom); Python nodes: 3
+    grads = fn(grad_output, *([None] * (n_out - 1)))
+    if not isinstance(grads, (tuple, list)):
+        grads = (grads,)
+    with torch.no_grad():
+        for leaf, g in zip(leaves, grads):
+            if leaf is not None and g is not None:
+                leaf.grad = g if leaf.grad is None else leaf.grad.add_(g)
+    return True
+
+
 class ViewStreams:
     """Round-robin HIP streams for the consecutive views of one rank.
 
@@ -485,8 +516,16 @@ class ViewStreams:
     accumulate into the same gradient buffers (FlatGrads); forwards only read the parameters.
     """
 
-    def __init__(self, device, n_streams: int = 2):
+    def __init__(self, device, n_streams: int = 2, group: int = 6, direct: bool = True, on_overflow: str = "recover"):
+        """group: views that share ONE pass of the autograd engine when run_view is given `grad_output` instead of a
+        backward function; direct: call the rasterizer's backward node on the calling thread instead when that is
+        equivalent (see run_view); on_overflow: the policy of the step's views -- "recover" (default: no view is lost, end_step
+        waits for the last view's header) or "drop" / "raise" (config.py: never waits)."""
         self.device = device
+        self.group = max(1, int(group))
+        self.direct = bool(direct)
+        self.on_overflow = on_overflow
+        self._deferred = []
         self.streams = [torch.cuda.Stream(device) for _ in range(max(1, n_streams))]
         # "backward of view i done" events, re-used round robin: an event is waited on (by the next view) right after it
         # is recorded, so a ring of two would do; one per stream keeps it obvious
@@ -507,22 +546,54 @@ class ViewStreams:
         # several views in flight: a forward must not wait for its own header copy (config "verify" does).  "recover": every
         # view's header is examined at end_step() and a view that overflowed its binning buffer -- the device-side guard
         # zeroed its gradients -- is run again in exact mode there, so no view of the step is lost
-        self._policy = config.overflow_policy("recover")
+        self._policy = config.overflow_policy(self.on_overflow)
         self._policy.__enter__()
         self._views = []
+        self._deferred = []
         self.recovered = 0
         # kernel shapes for a GPU shared by several views (render_bwd.hip blend_shape); never a correctness input
         _lib.tune_set("views_in_flight", len(self.streams))
+        # the step's accumulate-mode backward passes share the library's interleaved accumulator of the five small rows
+        # (lr_step_begin: what lr_views_accumulate does internally); end_step hands the rows to the .grad tensors
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            if L.lr_step_begin() < 0:                        # a step that never reached end_step()
+                L.lr_step_end(cur.cuda_stream)
+                L.lr_step_begin()
+        self._step_open = True
+
+    def _close_step(self, stream):
+        from . import _lib
+        if getattr(self, "_step_open", False):
+            self._step_open = False
+            with torch.cuda.device(self.device):
+                if _lib.lib().lr_step_end(stream.cuda_stream) < 0:
+                    _lib.raise_for(-1, "lr_step_end")
 
     def _pop_policy(self):
         from . import _lib
+        self._close_step(torch.cuda.current_stream(self.device))
         if getattr(self, "_policy", None) is not None:
             self._policy.__exit__(None, None, None)
             self._policy = None
             _lib.tune_set("views_in_flight", -1)
 
-    def run_view(self, forward_fn: Callable, backward_fn: Callable):
+    def run_view(self, forward_fn: Callable, backward_fn: Optional[Callable] = None, grad_output: Optional[torch.Tensor] = None):
+        """forward_fn() -> the view's output tensor, issued on the next stream of the ring.  Then EITHER
+        backward_fn(out): the view's backward right away (its own pass of the autograd engine), chained behind the previous
+            view's by an event; OR
+        grad_output: dL/d out -- the backward is DEFERRED and shares one engine pass (`torch.autograd.backward` over the
+            group's outputs) with up to `group` consecutive views.  The engine hands a backward to its device thread and waits
+            for it: ~130 us of host time per call on this path (profiles/r04d_host_breakdown.txt), more than a view's forward
+            and backward launches together; one pass per group leaves ~20 us per view.  Every node still runs on the stream
+            of its own forward, and accumulating backward passes are chained on the device by the binding itself
+            (csrc/torch_ext.cpp AccumulateChain), so the gradients are those of the per-view form.  With `direct` (default)
+            and `out` the rasterizer's own output over LEAF inputs under fused gradient accumulation, there is nothing for the
+            engine to do at all -- one node, gradients added in place by its kernels -- and the node is called right here, on
+            this thread (_direct_backward): ~25 us instead of the engine's ~110 us per view, no grouping needed."""
         from . import config
+        if (backward_fn is None) == (grad_output is None):
+            raise ValueError("give exactly one of backward_fn / grad_output")
         s = self.streams[self._i % len(self.streams)]
         # set_stream instead of the `with torch.cuda.stream(s)` context: the context manager's save / restore per view is
         # ~10 us of host time on a path that is host bound; end_step() puts the caller's stream back
@@ -530,28 +601,51 @@ class ViewStreams:
         try:
             n0 = len(config._pending)
             out = forward_fn()
-            entry = config._pending[-1] if len(config._pending) > n0 else None      # this view's header copy, if async
-            if self._prev_bwd is not None:
-                s.wait_event(self._prev_bwd)
-            backward_fn(out)
-            ev = self._events[self._i % len(self._events)]
-            ev.record(s)
-            self._prev_bwd = ev
+            entry = config._pending[-1] if len(config._pending) > n0 else None      # this view's header, if async
+            if backward_fn is not None:
+                if self._prev_bwd is not None:
+                    s.wait_event(self._prev_bwd)
+                backward_fn(out)
+                ev = self._events[self._i % len(self._events)]
+                ev.record(s)
+                self._prev_bwd = ev
+                redo = backward_fn
+            else:
+                if not (self.direct and _direct_backward(out, grad_output)):
+                    self._deferred.append((out, grad_output))
+                    if len(self._deferred) >= self.group:
+                        self._flush()
+                redo = lambda o, g=grad_output: torch.autograd.backward([o], [g])
             if entry is not None:
-                self._views.append((entry, forward_fn, backward_fn))
+                self._views.append((entry, forward_fn, redo))
+        except BaseException:
+            if self._caller is not None:
+                torch.cuda.set_stream(self._caller)
+            self._deferred = []
+            self._pop_policy()
+            raise
+        self._i += 1
+
+    def _flush(self):
+        if self._deferred:
+            outs, grads = zip(*self._deferred)
+            self._deferred = []
+            torch.autograd.backward(list(outs), list(grads))
+
+    def end_step(self):
+        from . import config
+        try:
+            self._flush()
         except BaseException:
             if self._caller is not None:
                 torch.cuda.set_stream(self._caller)
             self._pop_policy()
             raise
-        self._i += 1
-
-    def end_step(self):
-        from . import config
         cur = self._caller if self._caller is not None else torch.cuda.current_stream(self.device)
         torch.cuda.set_stream(cur)
         for s in self.streams:
             cur.wait_stream(s)
+        self._close_step(cur)                                # after every view of the step, before any re-run
         self._caller = None
         views, self._views = getattr(self, "_views", []), []
         try:

@@ -33,6 +33,21 @@ class GaussianRasterizationSettings(NamedTuple):
     debug: bool
 
 
+def _take_ticket():
+    """The early-header request of a forward is ALWAYS withdrawn, also when the forward raised: a request left
+    behind would make an unrelated later forward on this thread post a ticket nobody takes.  If the forward failed after the
+    ticket was posted, a ticket of the copy-and-event kind is waited for once, which releases it (log tickets hold nothing)."""
+    import sys
+    ticket = _C.take_early_ticket()
+    if sys.exc_info()[0] is not None and 0 <= ticket < (1 << 40):
+        try:
+            _C.header_poll(ticket, True)
+        except Exception:
+            pass
+        return -1
+    return ticket
+
+
 def _snapshot(args, path):
     torch.save(tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args), path)
 
@@ -50,14 +65,19 @@ class _RasterizeGaussians(torch.autograd.Function):
         capacity = config.capacity_for(means3D, rs)
         verifying = config.verifying(capacity)
         try:
+            ticket = -1
             if verifying:
                 _C.request_early_header()
-            num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
-                *args, binning_capacity=capacity)
+            try:
+                num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(
+                    *args, binning_capacity=capacity)
+            finally:
+                if verifying:
+                    ticket = _take_ticket()
             # policy "verify": every kernel of the forward is enqueued; wait for the copy of the header the library posted
             # after the scan, and if the view needs more instances than the buffer holds render it again in exact mode --
             # what is returned is always a complete image
-            if verifying and config.verify(means3D, rs, _C.take_early_ticket()):
+            if verifying and config.verify(means3D, rs, ticket):
                 capacity = 0
                 num_rendered, color, depth, radii, geom, binning, img = _C.rasterize_gaussians(*args, binning_capacity=0)
         except Exception:
@@ -124,12 +144,17 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
         return _C.rasterize_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
                                      rs.viewmatrix, rs.projmatrix, rs.campos, rs.scale_modifier, rs.tanfovx, rs.tanfovy,
                                      rs.image_height, rs.image_width, rs.sh_degree, rs.prefiltered, cap, fused)
+    ticket = -1
     if verifying:
         _C.request_early_header()
-    color, radii, depth, geom = run(capacity)
+    try:
+        color, radii, depth, geom = run(capacity)
+    finally:
+        if verifying:
+            ticket = _take_ticket()
     # policy "verify" (config.py): the whole forward is enqueued; if the view needs more instances than its buffer holds it is
     # rendered again in exact mode -- what is returned is always a complete image (the first node is simply dropped)
-    if verifying and config.verify(means3D, rs, _C.take_early_ticket()):
+    if verifying and config.verify(means3D, rs, ticket):
         capacity = 0
         color, radii, depth, geom = run(0)
     config.note_forward(means3D, rs, _C.last_num_rendered(), geom, capacity)
@@ -151,10 +176,15 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 rs.bg, xyz, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.sh_degree, rs.campos, rs.debug,
                 binning_capacity=cap)
+        ticket = -1
         if verifying:
             _C.request_early_header()
-        num_rendered, color, depth, radii, geom, binning, img = run(capacity)
-        if verifying and config.verify(xyz, rs, _C.take_early_ticket()):       # overflowed: an exact-mode render instead
+        try:
+            num_rendered, color, depth, radii, geom, binning, img = run(capacity)
+        finally:
+            if verifying:
+                ticket = _take_ticket()
+        if verifying and config.verify(xyz, rs, ticket):       # overflowed: an exact-mode render instead
             capacity = 0
             num_rendered, color, depth, radii, geom, binning, img = run(0)
         config.note_forward(xyz, rs, num_rendered, geom, capacity)

@@ -231,8 +231,16 @@ def test_header_tickets(hip_device):
     with pytest.raises(RuntimeError, match="ticket"):
         _C.header_poll(tickets[0], False)                                       # released by the poll above
     with pytest.raises(RuntimeError, match="ticket"):
-        _C.header_poll(1 << 40, False)
+        _C.header_poll((1 << 39) + 12345, False)
     assert _C.header_post(out[4]) in tickets                                    # released tickets are handed out again
+    # the forward log: an async-mode forward leaves its header in host-visible memory by itself (no copy, no event); the
+    # ticket of the last one on this thread costs nothing and may be polled any number of times
+    out = _C.rasterize_gaussians(*args, binning_capacity=10_000_000)
+    t = _C.last_forward_ticket()
+    assert t >= (1 << 40)
+    assert _C.header_poll(t, True) == words[0] and _C.header_poll(t, False) == words[0]
+    _C.rasterize_gaussians(*args)                                               # an exact-mode forward has no log entry
+    assert _C.last_forward_ticket() == -1
     small = _C.rasterize_gaussians(*args, binning_capacity=100)
     assert _C.header_poll(_C.header_post(small[4]), True)[1] == 1               # overflow flag
 
@@ -351,7 +359,7 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     g = synthetic.upstream_grad(180, 320).to(hip_device)
     bg = torch.zeros(3, device=hip_device)
 
-    def run(n_streams):
+    def run(n_streams, grouped=False, direct=True):
         leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
         grads = parallel.FlatGrads(list(leaf.values()))
         m2d = torch.zeros(30_000, 3, device=hip_device, requires_grad=True)
@@ -364,26 +372,35 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
                 False, False)))
         config.set_fused_grad_accumulation(True)
         try:
-            pipe = parallel.ViewStreams(hip_device, n_streams)
+            pipe = parallel.ViewStreams(hip_device, n_streams, group=3, direct=direct)
             for _ in range(2):                      # two steps: buffers and events are re-used
                 grads.zero_()
                 m2d.grad.zero_()
                 pipe.begin_step()
                 for r in rast:
-                    pipe.run_view(lambda r=r: r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
-                                                shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0],
-                                  lambda col: col.backward(g))
+                    fwd = lambda r=r: r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                        shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0]
+                    if grouped:                     # three views per pass of the autograd engine (8 views: 3 + 3 + 2)
+                        pipe.run_view(fwd, grad_output=g)
+                    else:
+                        pipe.run_view(fwd, lambda col: col.backward(g))
                 pipe.end_step()
             torch.cuda.synchronize()
         finally:
             config.set_fused_grad_accumulation(False)
         return grads.flat.cpu().numpy().copy(), m2d.grad.cpu().numpy().copy()
 
-    (f1, m1), (f2, m2) = run(1), run(2)
+    (f1, m1), (f2, m2), (f3, m3), (f4, m4) = run(1), run(2), run(3, grouped=True, direct=False), run(3, grouped=True)
     assert np.abs(f1).max() > 0
     # the per-Gaussian sums run in a fixed order; only the 2-wave LDS adds inside a tile can reorder
     assert np.abs(f1 - f2).max() <= 1e-5 * np.abs(f1).max()
     assert np.abs(m1 - m2).max() <= 1e-5 * np.abs(m1).max()
+    # grouped backward passes: accumulation order differs (the engine runs a group's nodes last view first)
+    assert np.abs(f1 - f3).max() <= 1e-5 * np.abs(f1).max()
+    assert np.abs(m1 - m3).max() <= 1e-5 * np.abs(m1).max()
+    # the backward node called directly on the issuing thread (no engine): the per-view order, bit for bit the 2-stream result
+    assert np.array_equal(f2, f4) or np.abs(f1 - f4).max() <= 1e-5 * np.abs(f1).max()
+    assert np.abs(m1 - m4).max() <= 1e-5 * np.abs(m1).max()
 
 
 def test_view_pipeline_recovers_views_that_overflow_their_buffer(hip_device):

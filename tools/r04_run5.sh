@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 4, GPU call 5: grouped backward passes (one autograd engine pass per 6 views), forward log, no zeroing launch
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd $R
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests/test_gpu_parity.py tests/test_gpu_full.py tests/test_gpu_raw.py tests/test_gpu_fuzz.py tests/test_gpu_variants.py tests/test_cabi_and_api.py tests/test_gpu_distributed.py tests/test_gpu_ref_parity.py tests/test_gpu_shapes.py tests/test_gpu_training.py "tests/test_gpu_reference_stack.py::test_install_switches_the_unchanged_loop_onto_the_fused_pieces" "tests/test_gpu_reference_stack.py::test_unchanged_reference_loop_small_with_densification" -q -m gpu 2>&1 | tail -15
+timeout 600 python tools/host_breakdown.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04e_host_breakdown.txt
+timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/r04e_bench_c3.json 2> gpurun_out/r04e_bench_c3.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r04e_bench_c3.json').read().strip().splitlines()[-1])
+print(d['value'], d['sustained'], {k:v for k,v in d['entry_points'].items() if k!='note'})
+print(d['roofline']['stage_ms_per_view'])
+PY
