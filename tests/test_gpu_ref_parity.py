@@ -53,6 +53,14 @@ def test_hip_reproduces_committed_reference_outputs(hip_device, name):
         # to 1e-5 (the reference's own builds do not either) -- judged against a float64 evaluation in
         # test_ill_conditioned_splats_against_the_float64_blend below
         assert np.isfinite(color).all() and np.isfinite(depth).all() and all(np.isfinite(g).all() for g in grads.values())
+        # a BOUNDED agreement with the committed reference image all the same -- a blend regression confined to
+        # high-overdraw pixels must not pass unseen: most pixels agree to the usual tolerance, the rest stay close
+        cerr = np.abs(color - fx[name + "/color"]).max(axis=0)
+        print(f"needles vs the committed reference image: median {np.median(cerr):.2e}, pixels beyond 1e-5: "
+              f"{(cerr > 1e-5).mean():.3f}, beyond 1e-3: {(cerr > 1e-3).mean():.4f}, max {cerr.max():.2e}")
+        # measured on MI355X: median 1.25e-5, 55 % of the pixels beyond 1e-5 (no two float32 evaluations of these conics agree
+        # there), 0.18 % beyond 1e-3, one pixel off by a whole layer
+        assert np.median(cerr) <= 5e-5 and (cerr > 1e-3).mean() <= 0.01 and np.percentile(cerr, 99) <= 1e-3
         return
     # pixels where the reference itself sits within an ulp of a discrete threshold: flagged by the (bit-identical)
     # restatement, which records them while blending

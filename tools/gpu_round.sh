@@ -3,7 +3,7 @@
 #   bench.py (driver settings) -> gpurun_out/<tag>_bench_c3.json
 #   rocprofv3 --kernel-trace --stats of the same command (default streams and --streams 1) -> <tag>_c3_kernel_stats_*.md
 #   PMC passes (tools/pmc_run.sh) -> <tag>_pmc_c3.json, stamped with lr_version()
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 mkdir -p $R/gpurun_out

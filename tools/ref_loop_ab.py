@@ -24,20 +24,28 @@ def main():
     base, hidden = _perturbed(P, 41)
     targets, depths = _targets(hidden, cams)
     order = [int(i) for i in np.random.default_rng(9).integers(0, 8, size=iters)]
+    import luciddreamer_amd
     modes = {"exact": lambda: config.set_async(False), "verify": lambda: config.set_async(True),
              "drop": lambda: config.set_async(True, on_overflow="drop")}
+    if "--install" in sys.argv:                              # the same loop after luciddreamer_amd.install(R)
+        modes = {k + "+install": v for k, v in modes.items()}
     res = {k: [] for k in modes}
     for rnd in range(3):
         for name, setup in modes.items():
             config.reset()
             setup()
             with ref_loop.stack("ours") as (R, dev):
-                gm = ref_loop.model_from_cloud(R, base, dev)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                out = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - t0
+                handle = luciddreamer_amd.install(R) if name.endswith("+install") else None
+                try:
+                    gm = ref_loop.model_from_cloud(R, base, dev)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    out = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - t0
+                finally:
+                    if handle is not None:
+                        luciddreamer_amd.uninstall(handle)
             config.drain()
             if rnd:                                         # round 0 warms up (MIOpen, allocator)
                 res[name].append(dt / iters * 1e3)
