@@ -107,6 +107,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
     for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off));
     return v;
 }
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 
 // s_acc column of each term: 0 sum D dx, 1 sum D dy, 2 sum D dx^2, 3 sum D dx dy, 4 sum D dy^2, 5 sum D (= dop), 6 dr, 7 dg,
 // 8-11 db (one column per 16-lane row); the flush turns columns 0-4 into GradRec's dmx, dmy, dca, dcb, dcc (same float order)
@@ -138,7 +139,10 @@ struct BwdPix {
 // FIRSTM / FIRSTC: the lane's moment / colour sums are ASSIGNED (first pixel of the lane for this candidate) instead of
 // accumulated -- `0 + a * b` is not foldable under IEEE rules and would cost an extra v_fma per term next to the product
 // that is needed anyway.
-template <bool FIRSTM, bool FIRSTC>
+// CHECK_LAST: the `pos < last` test is compiled in.  A pixel the forward never stopped (T stayed above 1e-4) carries last = the
+// list length, so the test can only fail for pixels that DID stop; a wave none of whose pixels stopped (99 % of the waves of a
+// C3 view; most of a dense one do have stopped pixels) walks its candidates through the copy of the loop without it.
+template <bool FIRSTM, bool FIRSTC, bool CHECK_LAST>
 __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float Bd, const float Cdd, const float gx,
                                           const float op, const float cr, const float cg, const float cb, const uint32_t pos,
                                           float& sD, float& sMx, float& sMxx, float& sR, float& sG, float& sB)
@@ -148,7 +152,7 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
     const float Graw = gauss_exp2(power);
     const float araw = fminf(0.99f, op * Graw);
     // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped
-    const bool v = pos < p.last && power <= 0.0f && araw >= 1.0f / 255.0f;
+    const bool v = (!CHECK_LAST || pos < p.last) && power <= 0.0f && araw >= 1.0f / 255.0f;
     const float alpha = v ? araw : 0.f;
     const float G = v ? Graw : 0.f;
     const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);                 // one v_rcp per pixel
@@ -176,7 +180,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-             char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
+             char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr, int force_check)
 {
     constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
@@ -229,6 +233,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
     const uint32_t lastL = wave_max_u32(PA.last), lastR = QUAD ? 0u : wave_max_u32(PB.last);   // per quadrant
     const uint32_t wave_last = max(lastL, lastR);                   // nothing at or behind this matters to the wave
+    // did the forward stop any pixel of this wave early?  (pixels outside the image carry T = 0 and dL = 0: whatever they step
+    // through contributes exact zeros, so they do not count)
+    const bool any_stopped = force_check != 0 ||
+                             __ballot((insA && PA.last < (uint32_t)total) || (insB && PB.last < (uint32_t)total)) != 0ull;
     const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
     const float ddely_dy = (float)(0.5 * H);
 
@@ -298,6 +306,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             }
             const uint64_t maskL = __ballot(hitL), maskR = QUAD ? 0ull : __ballot(hitR);
             uint64_t mask = maskL | maskR;
+            auto walk = [&](auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
                 mask &= mask - 1;
@@ -309,8 +319,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
-                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true, CHECK>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false, CHECK>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
@@ -336,6 +346,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                     }
                 }
             }
+            };
+            if (any_stopped) walk(BoolTag<true>{}); else walk(BoolTag<false>{});
         }
         lds_barrier();
         if (tid < cnt) {
@@ -376,7 +388,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
                   const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
                   const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
-                  char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr)
+                  char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr, int force_check)
 {
     __shared__ float4 s_q0[BATCH];      // as k_render_bwd
     __shared__ float2 s_q1[BATCH];
@@ -467,6 +479,9 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
         const uint64_t m2 = __ballot(inb && pos_l < last2 && (my_hit & 0x00ff0000u) != 0u);
         const uint64_t m3 = __ballot(inb && pos_l < last3 && (my_hit & 0xff000000u) != 0u);
         uint64_t mask = (m0 | m1) | (m2 | m3);
+        // (always the copy WITH the `pos < last` test: a second copy of this loop costs the 64-VGPR budget 28 more spilled bytes
+        //  and the kernel 5 % -- measured 96.0 -> 101.0 us at C3, profiles/r04i_ab_bwd_nocheck_tile.json)
+        constexpr bool CHECK = true;
         while (mask) {
             const int j = __ffsll((long long)mask) - 1;       // staged order is already back to front
             mask &= mask - 1;
@@ -479,13 +494,13 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const bool h0 = (m0 >> j) & 1ull, h1 = (m1 >> j) & 1ull, h2 = (m2 >> j) & 1ull, h3 = (m3 >> j) & 1ull;
             if (h0 || h1) {
                 const float Bd = a.w * dysT, Cdd = (b.x * dysT) * dysT;                        // common.h gauss_power
-                if (h0) bwd_pixel<true, true>(P0, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
-                if (h1) bwd_pixel<false, false>(P1, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h0) bwd_pixel<true, true, CHECK>(P0, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h1) bwd_pixel<false, false, CHECK>(P1, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
             }
             if (h2 || h3) {
                 const float Bd = a.w * dysB, Cdd = (b.x * dysB) * dysB;
-                if (h2) bwd_pixel<true, false>(P2, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
-                if (h3) bwd_pixel<false, false>(P3, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h2) bwd_pixel<true, false, CHECK>(P2, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h3) bwd_pixel<false, false, CHECK>(P3, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
             }
             // the dy factors, per pixel pair (a pair shares its row)
             const float t1 = dysT * tD, t2 = dysB * bD;
@@ -521,8 +536,8 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
                       const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,                        \
                       const float* __restrict__ bg, const float* __restrict__ final_Ts,                                 \
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,                        \
-                      char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr
-#define LR_BWD_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr
+                      char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr, int force_check
+#define LR_BWD_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check
 // 64 VGPRs and 4.3 KB of LDS: 8 waves per SIMD, so the 8160 waves of a 1080p view are all resident at once (8192 slots).  The
 // tiles of a view carry nearly the same load (C3: 70 instances on average, 102 at most): with 7 per SIMD the last 992 waves
 // start when the first 7168 finish together and then run alone on their SIMDs, one instruction per ~5 cycles.
@@ -588,7 +603,9 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     static const int forced_red = [] { const char* e = getenv("LR_BWD_RED"); return e ? atoi(e) : -1; }();
     const int red = tune_get(TUNE_BWD_RED) >= 0 ? tune_get(TUNE_BWD_RED) : forced_red;
     const bool merge = red != 0;
-#define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr
+    // lr_tune_set("bwd_red", 4): every wave walks the copy of the loop WITH the `pos < last` test (A/B partner of the default)
+    const int force_check = red == 4 ? 1 : 0;
+#define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
     const int shape = blend_shape(num_tiles);
     if (shape == BLEND_TILE) {
         if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);

@@ -75,6 +75,29 @@ def test_backward_reductions_agree(hip_device, W, H):
         assert np.array_equal(again["grads"][k], outs[1]["grads"][k]), k
 
 
+@pytest.mark.parametrize("shape", [0, 1, 2])        # 2 waves x 2 pixels, 4 waves x 1 pixel, 1 wave x 4 pixels per tile
+@pytest.mark.parametrize("scale_mult", [1.0, 4.0])  # sparse overdraw (hardly a pixel stops early) / heavy overdraw (most do)
+def test_check_free_candidate_loop_is_bit_identical(hip_device, shape, scale_mult):
+    """A wave none of whose pixels the forward stopped early walks a copy of the candidate loop without the `pos < last` test
+    (render_bwd.hip bwd_pixel CHECK_LAST); lr_tune_set("bwd_red", 4) sends every wave through the copy WITH it.  The test can
+    only fail for stopped pixels, so the two must give the same bits -- on a scene where nearly every wave takes the shortcut
+    and on one where nearly none does."""
+    cam, cloud = hp.box_setup(30_000, 640, 360, seed=3, scale_mult=scale_mult)
+    g = synthetic.upstream_grad(360, 640)
+    _lib.tune_set("blend_quad", shape)
+    try:
+        _lib.tune_set("bwd_red", 4)
+        a = _run(cloud, cam, hip_device, g)
+        _lib.tune_set("bwd_red", 1)
+        b = _run(cloud, cam, hip_device, g)
+    finally:
+        _lib.tune_set("bwd_red", -1)
+        _lib.tune_set("blend_quad", -1)
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    assert any(np.abs(a["grads"][k]).max() > 0 for k in a["grads"])
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_compiled_and_python_autograd_nodes_agree(hip_device, fused):
     """The operator's autograd node exists twice: compiled (csrc/torch_ext.cpp RasterizeFn, the default) and in Python
