@@ -149,18 +149,21 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
 {
     const float dx = gx - p.pxf;
     const float power = gauss_power1(Ap, Bd, Cdd, dx);                     // log2(e) x the reference's power
-    const float Graw = gauss_exp2(power);
-    const float araw = fminf(0.99f, op * Graw);
-    // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped
-    const bool v = (!CHECK_LAST || pos < p.last) && power <= 0.0f && araw >= 1.0f / 255.0f;
-    const float alpha = v ? araw : 0.f;
-    const float G = v ? Graw : 0.f;
+    const float t = op * gauss_exp2(power);                                // opacity x G: alpha before the 0.99 clamp
+    // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped (the
+    // clamp at 0.99 cannot change the outcome of the 1/255 test, so it is taken on the unclamped product).  ONE select: the
+    // masked product serves as alpha (clamped) and, unclamped, as the weight of the geometric gradients -- what the lane sums
+    // accumulate is opacity x G x dL/dalpha (the reference's dL/dG chain rule carries the opacity factor anyway,
+    // backward.cu:563-570); the flush divides the one sum that wants G x dL/dalpha alone (dL/dopacity) by the opacity
+    const bool v = (!CHECK_LAST || pos < p.last) && power <= 0.0f && t >= 1.0f / 255.0f;
+    const float tm = v ? t : 0.f;
+    const float alpha = fminf(0.99f, tm);
     const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);                 // one v_rcp per pixel
     p.T = p.T * rinv;
     const float dchan = alpha * p.T;
     const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;                // colour of this Gaussian . dL/dpixel
     const float d = cdl - p.A;
-    const float dop = G * (d * p.T);                                       // G * dL/dalpha
+    const float dop = tm * (d * p.T);                                      // opacity x G x dL/dalpha
     p.A = __builtin_fmaf(alpha, d, p.A);                                   // a skipped layer (alpha = 0) leaves A as it is
     const float mx = dop * dx;
     if (FIRSTM) { sD = dop; sMx = mx; sMxx = mx * dx; }
@@ -365,10 +368,13 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const float4 q0 = s_q0[tid]; const float2 q1 = s_q1[tid];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;   // conic back from the scaled staging
-            const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
+            // the moment sums carry the opacity factor already (bwd_pixel); dL/dopacity = sum G dL/dalpha = a9[5] / opacity
+            // (an instance with opacity <= 0 never passes the 1/255 test: all its sums are zero)
+            const float sx = a9[0], sy = a9[1], h = -0.5f;
+            const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;      // 1 ulp: the sum itself carries more
             float4* slot = inst_grad + 3 * (size_t)s_id[tid];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
-            slot[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
+            slot[1] = make_float4(h * a9[4], dopac, a9[6], a9[7]);
             slot[2] = make_float4(db, 0.f, 0.f, 0.f);
         }
     }
@@ -523,10 +529,11 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const float4 q0 = s_q0[l]; const float2 q1 = s_q1[l];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;
-            const float sx = o * a9[0], sy = o * a9[1], h = -0.5f * o;
+            const float sx = a9[0], sy = a9[1], h = -0.5f;          // as k_render_bwd: the sums carry the opacity factor
+            const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;      // 1 ulp: the sum itself carries more
             float4* slot = inst_grad + 3 * (size_t)s_id[l];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
-            slot[1] = make_float4(h * a9[4], a9[5], a9[6], a9[7]);
+            slot[1] = make_float4(h * a9[4], dopac, a9[6], a9[7]);
             slot[2] = make_float4(db, 0.f, 0.f, 0.f);
         }
     }
