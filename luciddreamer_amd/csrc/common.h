@@ -226,11 +226,29 @@ __device__ __forceinline__ float cull_qmax(float opacity)
 // Exponent of a splat at a pixel (offsets dx, dy from the centre):
 //   power = -0.5 (a dx^2 + c dy^2) - b dx dy  (forward.cu:332-334)  =  (Ap dx + Bp dy) dx + Cp dy dy
 // with Ap = -0.5 a, Bp = -b, Cp = -0.5 c formed once per Gaussian when it is staged, and Bd = Bp dy, Cdd = (Cp dy) dy
-// formed once per candidate and lane (two pixels of a lane share their row).  ONE definition shared by the blend forward
-// and backward, so both kernels evaluate alpha with the same operations.
+// formed once per candidate and lane (the pixels of a lane that share a row share them).  ONE definition for the blend
+// forward and every shape of the blend backward -- and the ROUNDING is part of the definition: the backward re-decides
+// `alpha >= 1/255` for every (pixel, candidate) pair, and a layer the forward blended must be a layer the backward
+// differentiates.  Left to -ffp-contract=fast the compiler contracted the same source differently per call site (the
+// forward and the one-pixel-per-lane backward fused the last product of Cdd into the final add, the two- and four-pixel
+// shapes rounded Cdd first): alphas one ulp apart, and on the handful of pixels per view where alpha sits within an ulp of
+// 1/255 the backward differentiated a layer the forward had skipped (or the reverse) -- 1-5 gradient rows per view moved by
+// up to 1.5e-3 of their tensor's maximum and the shapes disagreed with each other on them (tools/shape_vs_oracle.py).
+// So: two rounded products, two explicit FMAs, no contraction across the helpers.
+__device__ __forceinline__ float gauss_bd(float Bp, float dy)
+{
+#pragma clang fp contract(off)
+    return Bp * dy;
+}
+__device__ __forceinline__ float gauss_cdd(float Cp, float dy)
+{
+#pragma clang fp contract(off)
+    const float t = Cp * dy;
+    return t * dy;
+}
 __device__ __forceinline__ float gauss_power1(float Ap, float Bd, float Cdd, float dx)
 {
-    return (Ap * dx + Bd) * dx + Cdd;
+    return __builtin_fmaf(__builtin_fmaf(Ap, dx, Bd), dx, Cdd);
 }
 // The blend kernels stage Ap, Bp, Cp (and the cull threshold qmax, which box_hit compares with the same quadratic form)
 // multiplied by log2(e), so that G = exp(power) is one v_exp_f32 of the Horner value: the multiply of __expf leaves the

@@ -320,7 +320,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float2 b = s_q1[j];                         // Cp, opacity
                 const float4 c = s_q2[j];
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
-                const float Bd = a.w * dys, Cdd = (b.x * dys) * dys;                           // common.h gauss_power
+                const float Bd = gauss_bd(a.w, dys), Cdd = gauss_cdd(b.x, dys);                           // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
                 if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true, CHECK>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false, CHECK>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
@@ -499,12 +499,12 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             float tD = 0.f, tMx = 0.f, tMxx = 0.f, bD = 0.f, bMx = 0.f, bMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
             const bool h0 = (m0 >> j) & 1ull, h1 = (m1 >> j) & 1ull, h2 = (m2 >> j) & 1ull, h3 = (m3 >> j) & 1ull;
             if (h0 || h1) {
-                const float Bd = a.w * dysT, Cdd = (b.x * dysT) * dysT;                        // common.h gauss_power
+                const float Bd = gauss_bd(a.w, dysT), Cdd = gauss_cdd(b.x, dysT);                        // common.h gauss_power
                 if (h0) bwd_pixel<true, true, CHECK>(P0, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
                 if (h1) bwd_pixel<false, false, CHECK>(P1, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
             }
             if (h2 || h3) {
-                const float Bd = a.w * dysB, Cdd = (b.x * dysB) * dysB;
+                const float Bd = gauss_bd(a.w, dysB), Cdd = gauss_cdd(b.x, dysB);
                 if (h2) bwd_pixel<true, false, CHECK>(P2, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
                 if (h3) bwd_pixel<false, false, CHECK>(P3, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
             }

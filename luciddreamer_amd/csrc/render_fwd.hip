@@ -144,7 +144,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float4 c = s_q2[j];
                 const uint32_t pos0 = (uint32_t)(base + j);
                 const float dy = a.y - pyf;
-                const float Bd = a.w * dy, Cdd = (b.x * dy) * dy;                              // common.h gauss_power
+                const float Bd = gauss_bd(a.w, dy), Cdd = gauss_cdd(b.x, dy);                             // common.h gauss_power
                 fwd_pixel(A, done, a.z, Bd, Cdd, a.x - pxf, b.y, c.x, c.y, c.z, b.z, pos0);
             }
             if (done == ~0ull) { wave_done = true; break; }             // all 64 pixels are finished

@@ -98,6 +98,32 @@ def test_check_free_candidate_loop_is_bit_identical(hip_device, shape, scale_mul
     assert any(np.abs(a["grads"][k]).max() > 0 for k in a["grads"])
 
 
+def test_backward_shapes_differentiate_the_layers_the_forward_blended(hip_device):
+    """The backward re-decides `alpha >= 1/255` per (pixel, candidate) pair, so its alpha must be the forward's BIT FOR BIT
+    (common.h gauss_bd / gauss_cdd / gauss_power1: explicit roundings and FMAs).  Before round 4 the compiler contracted the
+    shared source differently per call site: the forward and the one-pixel-per-lane shape fused the last product of the
+    exponent into the final add, the two- and four-pixel shapes rounded it first -- on C3 views 15 and 18 one to four
+    Gaussians per view sat on a pixel where that ulp decided the 1/255 test, their gradient rows moved by up to 1.5e-3 of
+    the tensor's maximum and the shapes disagreed with each other (tools/shape_vs_oracle.py).  Now every shape must give
+    the same rows to float summation order."""
+    P = 1_000_000
+    cloud = synthetic.make_cloud(P, "band", 0)
+    path = cameras.rotate360_path(1920, 1080, n_views=30)
+    g = synthetic.upstream_grad(1080, 1920)
+    try:
+        for vi in (15, 18):
+            outs = []
+            for shape in (0, 1, 2):
+                _lib.tune_set("blend_quad", shape)
+                outs.append(hp.run_hip(cloud, path[vi], 3, torch.zeros(3), hip_device, g)["grads"])
+            for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations"):
+                scale = float(np.abs(outs[0][k]).max())
+                for o in outs[1:]:
+                    assert float(np.abs(o[k] - outs[0][k]).max()) <= 4e-6 * scale, (vi, k)
+    finally:
+        _lib.tune_set("blend_quad", -1)
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_compiled_and_python_autograd_nodes_agree(hip_device, fused):
     """The operator's autograd node exists twice: compiled (csrc/torch_ext.cpp RasterizeFn, the default) and in Python
