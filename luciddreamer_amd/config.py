@@ -114,6 +114,18 @@ def current_policy() -> str:
     return st[-1] if st else _on_overflow
 
 
+def set_strict_parity(enabled: bool):
+    """Strict evaluation of the blend (csrc/common.h gauss_weight<STRICT>): alpha from the reference's own expression in the
+    reference's operand order with every operation rounded on its own and expf -- the float operations of the reference
+    compiled without contraction -- instead of the Horner form with exp2 on pre-scaled coefficients.  Every discrete decision
+    of the blend then falls as it does in the reference: images agree within 1e-5 on EVERY pixel (the default agrees outside
+    the 0-3 pixels per 1080p view that sit within an ulp of a threshold) and no gradient row needs an exemption.  About 15 more
+    instructions per pixel step in both blend kernels: a parity instrument, not the default.  Process-wide; do not change it
+    between a forward and its backward."""
+    from . import _lib
+    _lib.tune_set("strict", 1 if enabled else -1)
+
+
 def set_fused_grad_accumulation(enabled: bool):
     """When on, the backward of the rasterizer op adds the gradient of every LEAF input whose .grad tensor
     already exists (contiguous float32) directly into that .grad inside the HIP kernel -- touching only the

@@ -250,6 +250,37 @@ __device__ __forceinline__ float gauss_power1(float Ap, float Bd, float Cdd, flo
 {
     return __builtin_fmaf(__builtin_fmaf(Ap, dx, Bd), dx, Cdd);
 }
+// STRICT evaluation (lr_tune_set("strict", 1); luciddreamer_amd.config.set_strict_parity): the reference's own expression in
+// the reference's operand order, every operation rounded on its own, and expf --
+//     power = -0.5f * (a dx dx + c dy dy) - b dx dy;   alpha = min(0.99f, opacity * exp(power))      (forward.cu:332-337)
+// -- i.e. exactly the float operations of the reference compiled without contraction (oracle/_ref, oracle/raster_oracle.c), so
+// that every discrete decision of the blend (power > 0, alpha < 1/255, T (1 - alpha) < 1e-4) falls as it does there: images
+// within 1e-5 on EVERY pixel instead of "outside the 0-3 threshold pixels of a view".  ~15 more instructions per pixel step
+// (nine roundings instead of two FMAs, a range-reduced exp instead of v_exp_f32): a parity instrument, not the default.
+// q = {a, b, c} raw conic in strict mode, {Ap, Bp, Cp} scaled otherwise; r0 / r1 = what is formed once per candidate and lane.
+template <bool STRICT>
+__device__ __forceinline__ void gauss_row(float qB, float qC, float dy, float& r0, float& r1)
+{
+    if (STRICT) { r0 = dy; r1 = 0.f; }
+    else { r0 = gauss_bd(qB, dy); r1 = gauss_cdd(qC, dy); }
+}
+__device__ __forceinline__ float gauss_power_strict(float ca, float cb, float cc, float dx, float dy)
+{
+#pragma clang fp contract(off)
+    return -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
+}
+// returns G = exp(power) and the value whose sign decides `power > 0` (log2(e) x power in the default mode)
+template <bool STRICT>
+__device__ __forceinline__ float gauss_weight(float qA, float qB, float qC, float r0, float r1, float dx, float& power)
+{
+    if (STRICT) {
+        power = gauss_power_strict(qA, qB, qC, dx, r0);
+        return expf(power);
+    }
+    power = gauss_power1(qA, r0, r1, dx);
+    return __builtin_amdgcn_exp2f(power);
+}
+
 // The blend kernels stage Ap, Bp, Cp (and the cull threshold qmax, which box_hit compares with the same quadratic form)
 // multiplied by log2(e), so that G = exp(power) is one v_exp_f32 of the Horner value: the multiply of __expf leaves the
 // per-pixel step of both kernels.  `power <= 0` reads the same on the scaled value.
@@ -323,7 +354,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): BLEND_QUAD = 4 waves per

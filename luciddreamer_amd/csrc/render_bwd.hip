@@ -142,14 +142,15 @@ struct BwdPix {
 // CHECK_LAST: the `pos < last` test is compiled in.  A pixel the forward never stopped (T stayed above 1e-4) carries last = the
 // list length, so the test can only fail for pixels that DID stop; a wave none of whose pixels stopped (99 % of the waves of a
 // C3 view; most of a dense one do have stopped pixels) walks its candidates through the copy of the loop without it.
-template <bool FIRSTM, bool FIRSTC, bool CHECK_LAST>
-__device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float Bd, const float Cdd, const float gx,
+template <bool FIRSTM, bool FIRSTC, bool CHECK_LAST, bool STRICT = false>
+__device__ __forceinline__ void bwd_pixel(BwdPix& p, const float qA, const float qB, const float qC, const float r0, const float r1,
+                                          const float gx,
                                           const float op, const float cr, const float cg, const float cb, const uint32_t pos,
                                           float& sD, float& sMx, float& sMxx, float& sR, float& sG, float& sB)
 {
     const float dx = gx - p.pxf;
-    const float power = gauss_power1(Ap, Bd, Cdd, dx);                     // log2(e) x the reference's power
-    const float t = op * gauss_exp2(power);                                // opacity x G: alpha before the 0.99 clamp
+    float power;                                                           // (log2(e) x) the reference's power
+    const float t = op * gauss_weight<STRICT>(qA, qB, qC, r0, r1, dx, power);   // opacity x G: alpha before the 0.99 clamp
     // reference tests (backward.cu:500-515): behind the pixel's last contributor, power > 0, alpha < 1/255 -> skipped (the
     // clamp at 0.99 cannot change the outcome of the 1/255 test, so it is taken on the unclamped product).  ONE select: the
     // masked product serves as alpha (clamped) and, unclamped, as the weight of the geometric gradients -- what the lane sums
@@ -177,7 +178,7 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float Ap, const float
 // Measured on MI355X, k_render_bwd single stream (profiles/r03b_ab_bwd_red_dpp_store.json): C3 100.6 -> 94.2 us, dense
 // 1 M cloud 526 -> 485 us, C5 shape (QUAD) 362 -> 324 us.
 // 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
-template <bool QUAD, bool MERGE>
+template <bool QUAD, bool MERGE, bool STRICT = false>
 __global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 4 : 7, 8)))
 k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
@@ -279,8 +280,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);        // as render_fwd.hip
-            s_q1[tid] = make_float2((-0.5f * LOG2E) * b.x, b.y);
+            // as render_fwd.hip: scaled exponent coefficients, or the raw conic in strict mode
+            s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            s_q1[tid] = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_id[tid] = e;
         }
@@ -320,10 +322,11 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float2 b = s_q1[j];                         // Cp, opacity
                 const float4 c = s_q2[j];
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
-                const float Bd = gauss_bd(a.w, dys), Cdd = gauss_cdd(b.x, dys);                           // common.h gauss_power
+                float r0, r1;
+                gauss_row<STRICT>(a.w, b.x, dys, r0, r1);                                       // common.h gauss_power
                 float sD = 0.f, sMx = 0.f, sMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true, CHECK>(PA, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
-                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false, CHECK>(PB, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (QUAD || ((maskL >> k) & 1ull)) bwd_pixel<true, true, CHECK, STRICT>(PA, a.z, a.w, b.x, r0, r1, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
+                if (!QUAD && ((maskR >> k) & 1ull)) bwd_pixel<false, false, CHECK, STRICT>(PB, a.z, a.w, b.x, r0, r1, a.x, b.y, c.x, c.y, c.z, pos, sD, sMx, sMxx, sR, sG, sB);
                 // both pixels of a lane share dy, so the dy factors are applied to the lane's sums
                 const float sMy = dys * sD, sMxy = dys * sMx;
                 const float sMyy = dys * sMy;
@@ -367,7 +370,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             }
             const float4 q0 = s_q0[tid]; const float2 q1 = s_q1[tid];
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
-            const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;   // conic back from the scaled staging
+            const float ca = STRICT ? q0.z : (-2.0f * LN2) * q0.z, cb = STRICT ? q0.w : -LN2 * q0.w,
+                        cc = STRICT ? q1.x : (-2.0f * LN2) * q1.x, o = q1.y;                   // conic (back from the scaled staging)
             // the moment sums carry the opacity factor already (bwd_pixel); dL/dopacity = sum G dL/dalpha = a9[5] / opacity
             // (an instance with opacity <= 0 never passes the 1/255 test: all its sums are zero)
             const float sx = a9[0], sy = a9[1], h = -0.5f;
@@ -500,13 +504,13 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const bool h0 = (m0 >> j) & 1ull, h1 = (m1 >> j) & 1ull, h2 = (m2 >> j) & 1ull, h3 = (m3 >> j) & 1ull;
             if (h0 || h1) {
                 const float Bd = gauss_bd(a.w, dysT), Cdd = gauss_cdd(b.x, dysT);                        // common.h gauss_power
-                if (h0) bwd_pixel<true, true, CHECK>(P0, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
-                if (h1) bwd_pixel<false, false, CHECK>(P1, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h0) bwd_pixel<true, true, CHECK>(P0, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h1) bwd_pixel<false, false, CHECK>(P1, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
             }
             if (h2 || h3) {
                 const float Bd = gauss_bd(a.w, dysB), Cdd = gauss_cdd(b.x, dysB);
-                if (h2) bwd_pixel<true, false, CHECK>(P2, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
-                if (h3) bwd_pixel<false, false, CHECK>(P3, a.z, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h2) bwd_pixel<true, false, CHECK>(P2, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h3) bwd_pixel<false, false, CHECK>(P3, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
             }
             // the dy factors, per pixel pair (a pair shares its row)
             const float t1 = dysT * tD, t2 = dysB * bD;
@@ -588,7 +592,8 @@ int blend_shape(int num_tiles)
     // instead of per half tile reached, the dy bookkeeping it adds is plain multiplies), but its 8160 waves -- all resident
     // at once, all in the same phase -- expose their staging latencies together when the kernel has the GPU to itself.  So:
     // one wave per tile when other views' kernels fill those gaps, the 2-wave shape for a lone view.
-    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_HALF;
+    // (strict mode -- lr_tune_set("strict", 1) -- exists in the 2-wave and 4-wave shapes)
+    return (views_in_flight() >= 2 && tune_get(TUNE_STRICT) <= 0) ? BLEND_TILE : BLEND_HALF;
 }
 
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
@@ -613,8 +618,13 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     // lr_tune_set("bwd_red", 4): every wave walks the copy of the loop WITH the `pos < last` test (A/B partner of the default)
     const int force_check = red == 4 ? 1 : 0;
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
-    const int shape = blend_shape(num_tiles);
-    if (shape == BLEND_TILE) {
+    int shape = blend_shape(num_tiles);
+    const bool strict = tune_get(TUNE_STRICT) > 0;
+    if (strict && shape == BLEND_TILE) shape = BLEND_HALF;
+    if (strict) {
+        if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<false, true, true>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
+    } else if (shape == BLEND_TILE) {
         if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
         else hipLaunchKernelGGL(k_render_bwd_tile, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
     } else if (shape == BLEND_QUAD) {

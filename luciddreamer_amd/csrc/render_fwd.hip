@@ -45,12 +45,14 @@ struct PixState { float T, Cr, Cg, Cb, D, acc; uint32_t last; };
 // One candidate for the 64 pixels of the wave.  The per-pixel predicates live in wave-uniform 64-bit lane masks
 // (v_cmp writes them to an SGPR pair; they are combined on the scalar unit and fed back to v_cndmask through
 // inverse_ballot at no VALU cost); `done` is the mask of finished pixels.
-__device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const float Ap, const float Bd, const float Cdd,
+template <bool STRICT>
+__device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const float qA, const float qB, const float qC,
+                                          const float r0, const float r1,
                                           const float dx, const float op, const float cr, const float cg, const float cb,
                                           const float depth, const uint32_t pos0)
 {
-    const float power = gauss_power1(Ap, Bd, Cdd, dx);               // log2(e) x the reference's power (staged coefficients)
-    const float alpha = fminf(0.99f, op * gauss_exp2(power));
+    float power;                                                      // log2(e) x the reference's power (staged coefficients)
+    const float alpha = fminf(0.99f, op * gauss_weight<STRICT>(qA, qB, qC, r0, r1, dx, power));
     const float test_T = p.T * (1.0f - alpha);
     // reference order of tests (forward.cu:331-347): power > 0 -> skip; alpha < 1/255 -> skip;
     // T*(1-alpha) < 1e-4 -> pixel done (this Gaussian is NOT blended)
@@ -68,6 +70,7 @@ __device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const flo
     }
 }
 
+template <bool STRICT>
 __global__ void __launch_bounds__(THREADS)
 k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
@@ -108,8 +111,9 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            s_q1[tid] = make_float4((-0.5f * LOG2E) * b.x, b.y, c.y, LOG2E * c.z);
+            // default: Ap, Bp, Cp and the cull threshold scaled by log2(e); strict: the conic and the threshold as they are
+            s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            s_q1[tid] = STRICT ? make_float4(b.x, b.y, c.y, c.z) : make_float4((-0.5f * LOG2E) * b.x, b.y, c.y, LOG2E * c.z);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
         }
@@ -125,7 +129,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                     const float4 a = s_q0[j];
                     const float4 b = s_q1[j];
                     const float2 r = s_q3[j];
-                    const float ca = -2.0f * a.z, cb = -a.w, cc = -2.0f * b.x;                  // conic x log2 e, like qmax
+                    const float ca = STRICT ? a.z : -2.0f * a.z, cb = STRICT ? a.w : -a.w, cc = STRICT ? b.x : -2.0f * b.x;   // conic (x log2 e, like qmax)
                     hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.w, bx0, bx1, by0, by1);
                     // the outcome is kept for the backward (common.h BinLayout::quad_hits): every position a pixel of this
                     // quadrant can have blended lies in a chunk this wave culled
@@ -144,8 +148,9 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const float4 c = s_q2[j];
                 const uint32_t pos0 = (uint32_t)(base + j);
                 const float dy = a.y - pyf;
-                const float Bd = gauss_bd(a.w, dy), Cdd = gauss_cdd(b.x, dy);                             // common.h gauss_power
-                fwd_pixel(A, done, a.z, Bd, Cdd, a.x - pxf, b.y, c.x, c.y, c.z, b.z, pos0);
+                float r0, r1;
+                gauss_row<STRICT>(a.w, b.x, dy, r0, r1);                                        // common.h gauss_power
+                fwd_pixel<STRICT>(A, done, a.z, a.w, b.x, r0, r1, a.x - pxf, b.y, c.x, c.y, c.z, b.z, pos0);
             }
             if (done == ~0ull) { wave_done = true; break; }             // all 64 pixels are finished
         }
@@ -173,8 +178,12 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_render_fwd, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid,
-                       rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
+    if (tune_get(TUNE_STRICT) > 0)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
+                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
+                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
 }
 
 }  // namespace lr

@@ -140,8 +140,54 @@ def test_c3_views_reference_self_disagreement_bounds_ours(hip_device):
     _within_reference_self_disagreement(recs)
 
 
+def test_strict_mode_agrees_with_the_strict_reference_on_every_pixel(hip_device):
+    """config.set_strict_parity(True): the blend evaluates alpha with the reference's own float operations (no contraction,
+    expf), so every discrete decision falls as in the reference's strict build: NO pixel beyond 1e-5 and NO gradient row
+    beyond 1e-4 on the C3 views -- including view 0, where the default mode differs on 3 pixels -- and the numbers go into the
+    calibration file next to the default mode's."""
+    from luciddreamer_amd import config
+    cloud = synthetic.make_cloud(1_000_000, "band", 0)
+    path = cameras.rotate360_path(1920, 1080, n_views=30)
+    P = 1_000_000
+    bg = torch.zeros(3)
+    recs = []
+    config.set_strict_parity(True)
+    try:
+        for i in (0, 11, 15, 19):
+            g = synthetic.upstream_grad(1080, 1920)
+            devr = _device_reference(cloud, path[i], bg, g, hip_device)
+            hip = hp.run_hip(cloud, path[i], 3, bg, hip_device, g)
+            d = disagreement(hip, devr, P)
+            print(f"strict mode, C3 view {i}:", json.dumps(d))
+            recs.append((i, d))
+    finally:
+        config.set_strict_parity(False)
+    old = json.load(open(OUT)) if os.path.exists(OUT) else {"cases": {}}
+    old["strict_mode_hip_vs_reference_gfx950"] = {f"c3_view{i}": d for i, d in recs}
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    json.dump(old, open(OUT, "w"), indent=1)
+    for i, d in recs:
+        assert d["radii_equal"] and d["pixels_beyond_1e-5"] == 0, (i, d)
+        assert all(v == 0 for v in d["rows_beyond_1e-4"].values()), (i, d)
+
+
 def test_c4_shape_reference_self_disagreement_bounds_ours(hip_device):
     cam, cloud = hp.box_setup(3_000_000, 2560, 1440)
     rec = _case("c4_shape", cloud, cam, hip_device)
     _store([rec])
     _within(rec, 64)
+    # the same in strict mode: no pixel, no row
+    from luciddreamer_amd import config
+    bg, g = torch.zeros(3), synthetic.upstream_grad(cam.image_height, cam.image_width, seed=0)
+    devr = _device_reference(cloud, cam, bg, g, hip_device)
+    config.set_strict_parity(True)
+    try:
+        hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+    finally:
+        config.set_strict_parity(False)
+    d = disagreement(hip, devr, 3_000_000)
+    print("strict mode, C4 shape:", json.dumps(d))
+    old = json.load(open(OUT))
+    old.setdefault("strict_mode_hip_vs_reference_gfx950", {})["c4_shape"] = d
+    json.dump(old, open(OUT, "w"), indent=1)
+    assert d["radii_equal"] and d["pixels_beyond_1e-5"] == 0 and all(v == 0 for v in d["rows_beyond_1e-4"].values()), d

@@ -124,6 +124,27 @@ def test_backward_shapes_differentiate_the_layers_the_forward_blended(hip_device
         _lib.tune_set("blend_quad", -1)
 
 
+@pytest.mark.parametrize("W,H", [(640, 360), (1280, 720)])      # 4-wave / 2-wave shape of k_render_bwd
+def test_strict_mode_against_the_oracle_without_exemptions(hip_device, W, H):
+    """Strict evaluation (config.set_strict_parity): image, depth and gradients against the CPU oracle with NO pixel masked
+    and no row exempt -- the oracle evaluates the same float operations."""
+    from luciddreamer_amd import config
+    cam, cloud = hp.box_setup(40_000, W, H, seed=11, scale_mult=1.5)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.1, 0.0, 0.2])
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    config.set_strict_parity(True)
+    try:
+        hip = hp.run_hip(cloud, cam, 3, bg, hip_device, g)
+    finally:
+        config.set_strict_parity(False)
+    assert np.array_equal(hip["radii"], ref["radii"])
+    cerr = np.abs(hip["color"] - ref["color"]).max()
+    derr = (np.abs(hip["depth"][0] - ref["depth"][0]) / np.maximum(1.0, np.abs(ref["depth"][0]))).max()
+    assert cerr <= hp.COLOR_ATOL and derr <= hp.DEPTH_RTOL, (float(cerr), float(derr))
+    hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+
+
 @pytest.mark.parametrize("fused", [False, True])
 def test_compiled_and_python_autograd_nodes_agree(hip_device, fused):
     """The operator's autograd node exists twice: compiled (csrc/torch_ext.cpp RasterizeFn, the default) and in Python
