@@ -252,6 +252,20 @@ def test_sparse_rows_exchange_equals_dense_all_reduce(tmp_path, P):
             assert 0 < sent <= touched and nbytes == sent * (4 * K + 4) + ((P + 1) // 2) * K * 4 and dense_bytes == 2 * (P * K * 4) // 2
 
 
+@pytest.mark.timeout(600)
+def test_sparse_rows_exchange_three_ranks(tmp_path):
+    """Three ranks: an owner adds up to two foreign contributions per row, source by source in rank order -- replicas identical,
+    the sum equal to the dense all-reduce's up to association."""
+    world, P = 3, 50
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path), P), nprocs=world, join=True)
+    rs = [np.load(tmp_path / f"sp{r}.npz") for r in range(world)]
+    for it in (0, 1):
+        for r in rs[1:]:
+            assert np.array_equal(rs[0][f"sparse{it}"], r[f"sparse{it}"]), "replicas diverged after the sparse exchange"
+        a, b = rs[0][f"sparse{it}"], rs[0][f"dense{it}"]
+        assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+
+
 def test_ring_allreduce_bytes_and_single_rank_sparse_is_a_no_op():
     assert parallel.ring_allreduce_bytes(59_000_000, 8) == 2 * 7 * 59_000_000 * 4 // 8
     assert parallel.ring_allreduce_bytes(10, 1) == 0
