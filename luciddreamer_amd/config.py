@@ -228,9 +228,18 @@ def verify(means3D, rs, ticket) -> bool:
     return over
 
 
+def take_last_entry():
+    """The deferred-check entry of the LAST forward issued by this thread ([ticket, key, policy, overflowed]), or None if that
+    forward posted none (exact mode, "verify", a sampled-out view); cleared by the call.  parallel.ViewStreams ties a view to
+    its header with this -- the length of `_pending` is no guide: the forward itself polls and retires older entries."""
+    entry, _tls.last_entry = getattr(_tls, "last_entry", None), None
+    return entry
+
+
 def note_forward(means3D, rs, num_rendered, geom, capacity):
     """After a forward.  Exact forwards feed the mark directly; async ones under "drop" / "raise" post the header copy that
     the deferred check examines ("verify" has looked at its own already)."""
+    _tls.last_entry = None
     if not _async or means3D.shape[0] == 0:
         return
     key = _key(means3D, rs)
@@ -250,4 +259,6 @@ def note_forward(means3D, rs, num_rendered, geom, capacity):
     # event, nothing enqueued); a library without one falls back to a 48-byte copy + event (lr_header_post).
     # Entry: [ticket, key, policy, overflowed (None until examined)]
     ticket = _C.last_forward_ticket() if hasattr(_C, "last_forward_ticket") else -1
-    _pending.append([ticket if ticket >= 0 else _C.header_post(geom), key, policy, None])
+    entry = [ticket if ticket >= 0 else _C.header_post(geom), key, policy, None]
+    _pending.append(entry)
+    _tls.last_entry = entry

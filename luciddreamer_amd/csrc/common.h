@@ -116,13 +116,14 @@ constexpr int TSORT_THREADS = 512;          // threads of k_tile_sort_large (bin
 constexpr int TSORT_MID_LDS = 4096;         // ... its bin entries (32 KB of words + 16 KB of bucket counters)
 constexpr int TSORT_BIG_LDS = 16384;        // ... entries sorted in LDS when the launch asks for 128 KB; beyond: in place in global memory
 constexpr int TSORT_BIG_BLOCKS = 256;
-constexpr int TSORT_CLASS_BLOCKS = 2048;     // grid cap of k_tile_sort_large (queue-fed)
+constexpr int TSORT_CLASS_BLOCKS = 2048;     // grid cap of part B of k_tile_sort_small (bins of 257..1024 entries)
+constexpr int TSORT_LARGE_BLOCKS = 768;      // grid cap of k_tile_sort_large (queue-fed; 48 KB of LDS each: three per CU are resident)
 struct PartPlan { int bins; int sub_shift; };   // bin = tile >> sub_shift (0 up to 16384 tiles)
 PartPlan part_plan(int num_tiles);
 
 // ---- buffer layouts ----------------------------------------------------------------------------
 struct GeomLayout {
-    size_t header, rec, clamped, tiles_touched, offsets, scan_sums, vis_list, hitrec, total;
+    size_t header, rec, clamped, tiles_touched, offsets, vis_list, hitrec, total;
 };
 inline GeomLayout geom_layout(int P) {
     GeomLayout L; size_t o = 0; size_t Pz = P > 0 ? (size_t)P : 1;
@@ -132,7 +133,6 @@ inline GeomLayout geom_layout(int P) {
     L.tiles_touched = o; o += align_up(Pz * 4);      // instances each Gaussian emits (after exact tile culling)
     L.vis_list = o;      o += align_up(Pz * 4);      // ids of the emitting Gaussians, index order (num_compact entries)
     L.offsets = o;       o += align_up(Pz * 4);      // first instance slot of vis_list[k]
-    L.scan_sums = o;     o += align_up(((Pz + SCAN_TILE - 1) / SCAN_TILE + 1) * 16);
     L.hitrec = o;        o += align_up(Pz * 16);     // HitRec per Gaussian (written for the emitting ones only)
     L.total = o;
     return L;

@@ -162,8 +162,9 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float qA, const float
     const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);                 // one v_rcp per pixel
     p.T = p.T * rinv;
     const float dchan = alpha * p.T;
-    const float cdl = cr * p.dLr + cg * p.dLg + cb * p.dLb;                // colour of this Gaussian . dL/dpixel
-    const float d = cdl - p.A;
+    // colour of this Gaussian . dL/dpixel, minus the colour behind: one fma chain started at -A (three instructions, not a
+    // dot product and a subtraction)
+    const float d = __builtin_fmaf(cb, p.dLb, __builtin_fmaf(cg, p.dLg, __builtin_fmaf(cr, p.dLr, -p.A)));
     const float dop = tm * (d * p.T);                                      // opacity x G x dL/dalpha
     p.A = __builtin_fmaf(alpha, d, p.A);                                   // a skipped layer (alpha = 0) leaves A as it is
     const float mx = dop * dx;
@@ -188,7 +189,8 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 {
     constexpr int BATCH = QUAD ? LR_QBATCH_BWD : BATCH2;
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
-    __shared__ float2 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity
+    __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity, -, -   (16-byte stride like s_q0 / s_q2: the
+                                        // three broadcast reads of a candidate share ONE address register)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ uint32_t s_id[BATCH];    // emission index (instance slot) of each staged element
     __shared__ uint32_t s_hit[BATCH];   // the forward's quadrant tests of each staged element (common.h BinLayout::quad_hits)
@@ -282,7 +284,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             const float4 a = g[0], b = g[1], c = g[2];
             // as render_fwd.hip: scaled exponent coefficients, or the raw conic in strict mode
             s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            s_q1[tid] = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
+            *reinterpret_cast<float2*>(&s_q1[tid]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
             s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
             s_id[tid] = e;
         }
@@ -319,7 +321,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 const int j = sb + k;
                 const uint32_t pos = (uint32_t)(pos_hi - j);
                 const float4 a = s_q0[j];
-                const float2 b = s_q1[j];                         // Cp, opacity
+                const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);   // Cp, opacity
                 const float4 c = s_q2[j];
                 const float dys = a.y - pyf;                      // both pixels of a lane share the row
                 float r0, r1;
@@ -368,7 +370,7 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
                 for (int a = 1; a < NACC; a++) v += s_acc[tid][a][k];      // fixed order over the waves
                 a9[k] = v;
             }
-            const float4 q0 = s_q0[tid]; const float2 q1 = s_q1[tid];
+            const float4 q0 = s_q0[tid]; const float2 q1 = *reinterpret_cast<const float2*>(&s_q1[tid]);
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = STRICT ? q0.z : (-2.0f * LN2) * q0.z, cb = STRICT ? q0.w : -LN2 * q0.w,
                         cc = STRICT ? q1.x : (-2.0f * LN2) * q1.x, o = q1.y;                   // conic (back from the scaled staging)
@@ -401,7 +403,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
                   char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr, int force_check)
 {
     __shared__ float4 s_q0[BATCH];      // as k_render_bwd
-    __shared__ float2 s_q1[BATCH];
+    __shared__ float4 s_q1[BATCH];
     __shared__ float4 s_q2[BATCH];
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_acc[BATCH * 12]; // one wave, one copy: a candidate is met once per batch, so its sums are plain stores
@@ -471,7 +473,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[l] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            s_q1[l] = make_float2((-0.5f * LOG2E) * b.x, b.y);
+            *reinterpret_cast<float2*>(&s_q1[l]) = make_float2((-0.5f * LOG2E) * b.x, b.y);
             s_q2[l] = make_float4(b.z, b.w, c.x, 0.f);
             s_id[l] = e;
         }
@@ -497,7 +499,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             mask &= mask - 1;
             const uint32_t pos = (uint32_t)(pos_hi - j);
             const float4 a = s_q0[j];
-            const float2 b = s_q1[j];                         // Cp, opacity
+            const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);   // Cp, opacity
             const float4 c = s_q2[j];
             const float dysT = a.y - pyTf, dysB = a.y - pyBf;
             float tD = 0.f, tMx = 0.f, tMxx = 0.f, bD = 0.f, bMx = 0.f, bMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
@@ -518,7 +520,8 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const float sMy = t1 + t2;
             const float sMxy = dysT * tMx + dysB * bMx;
             const float sMyy = dysT * t1 + dysB * t2;
-            float ra = tMx + bMx, rb = sMyy;
+            float ra = tMx + bMx;
+            float rb = sMyy;
             reduce8(ra, sMy, sMxx, sMxy, rb, sD, sR, sG);
             const float rc = row_merge3(ra, rb, sB);
             int jo = j * 12;
@@ -530,7 +533,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             float a9[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) a9[k] = s_acc[l * 12 + k];
-            const float4 q0 = s_q0[l]; const float2 q1 = s_q1[l];
+            const float4 q0 = s_q0[l]; const float2 q1 = *reinterpret_cast<const float2*>(&s_q1[l]);
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;
             const float sx = a9[0], sy = a9[1], h = -0.5f;          // as k_render_bwd: the sums carry the opacity factor
@@ -553,7 +556,7 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
 // tiles of a view carry nearly the same load (C3: 70 instances on average, 102 at most): with 7 per SIMD the last 992 waves
 // start when the first 7168 finish together and then run alone on their SIMDs, one instruction per ~5 cycles.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_vgpr(64)))
-k_render_bwd_tile(LR_BWD_PARAMS) { render_bwd_tile<48>(LR_BWD_PASS); }
+k_render_bwd_tile(LR_BWD_PARAMS) { render_bwd_tile<44>(LR_BWD_PASS); }
 // the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_render_bwd_tile7(LR_BWD_PARAMS) { render_bwd_tile<64>(LR_BWD_PASS); }

@@ -768,7 +768,8 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     // does not fit this launch's LDS is sorted in place in global memory).  Capped grid: a sparse view queues nothing
     const bool huge = bin_bound_hint / (long long)pp.bins > (long long)TSORT_MID_LDS;
     const uint32_t lds_entries = huge ? (uint32_t)TSORT_BIG_LDS : (uint32_t)TSORT_MID_LDS;
-    const int large_blocks = pp.bins < (huge ? TSORT_BIG_BLOCKS : TSORT_CLASS_BLOCKS) ? pp.bins : (huge ? TSORT_BIG_BLOCKS : TSORT_CLASS_BLOCKS);
+    const int large_cap = huge ? TSORT_BIG_BLOCKS : TSORT_LARGE_BLOCKS;        // what is resident at once; the queue is strided
+    const int large_blocks = pp.bins < large_cap ? pp.bins : large_cap;
     hipLaunchKernelGGL(k_tile_sort_large, dim3(large_blocks), dim3(TSORT_THREADS), (size_t)lds_entries * 8, s, pp.sub_shift,
                        slot_bits, num_tiles, lds_entries, bin_start, bin_total, words, point_list, ranges, big_queue);
     if (t) t->mark(4, s);

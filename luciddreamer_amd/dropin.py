@@ -95,7 +95,7 @@ def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=Tr
             _rebind(h, orig_render, render_, (gaussian_renderer,))
 
     if losses and loss is not None:
-        pair = PairedLoss()
+        pair = PairedLoss(fallback_l1=loss.l1_loss, fallback_ssim=loss.ssim)      # what the pair does not fuse stays the caller's
         for name in ("l1_loss", "ssim"):
             orig_fn, repl = getattr(loss, name), getattr(pair, name)
             h.set(loss, name, repl)

@@ -120,8 +120,17 @@ class PairedLoss:
     on the same (image, gt) tensors -- which is what the training loop does.  luciddreamer_amd.install() puts a pair of these
     in place of utils/loss.py's functions.  A call with other tensors (or ssim with another window) computes on its own."""
 
-    def __init__(self):
+    def __init__(self, fallback_l1=None, fallback_ssim=None):
+        """fallback_*: what a call the shared pass does not cover is handed to (install() passes the functions it replaces, so
+        the caller's own code keeps serving other window sizes, per-image means, host tensors); without one, l1 of anything
+        else is the reference's expression and such an ssim call raises."""
         self._key, self._pair = None, None
+        self._fallback_l1, self._fallback_ssim = fallback_l1, fallback_ssim
+
+    @staticmethod
+    def _fusable(a, b):
+        return (torch.is_tensor(a) and torch.is_tensor(b) and a.is_cuda and b.is_cuda and a.shape == b.shape and a.dim() >= 3
+                and a.shape[-3] == 3 and a.dtype == torch.float32 and b.dtype == torch.float32)
 
     def _get(self, a, b):
         key = (id(a), id(b), a._version, b._version, a.data_ptr(), b.data_ptr())
@@ -135,11 +144,15 @@ class PairedLoss:
     def l1_loss(self, network_output, gt):
         # only what the loop pairs with ssim goes through the shared pass: an RGB image against its target.  Anything else
         # (a depth map, a vector) is the reference's own expression, utils/loss.py:18-19
-        if network_output.shape != gt.shape or network_output.dim() != 3 or network_output.shape[0] != 3 or not network_output.is_cuda:
+        if not self._fusable(network_output, gt) or network_output.dim() != 3:
+            if self._fallback_l1 is not None:
+                return self._fallback_l1(network_output, gt)
             return torch.abs(network_output - gt).mean()
         return self._get(network_output, gt)[0]
 
     def ssim(self, img1, img2, window_size=11, size_average=True):
-        if window_size != 11 or not size_average:
-            raise NotImplementedError("fused ssim supports window_size=11, size_average=True")
+        if window_size != 11 or not size_average or not self._fusable(img1, img2):
+            if self._fallback_ssim is not None:
+                return self._fallback_ssim(img1, img2, window_size, size_average)
+            raise NotImplementedError("fused ssim: float32 [..., 3, H, W] device tensors, window_size=11, size_average=True")
         return self._get(img1, img2)[1]

@@ -599,9 +599,9 @@ class ViewStreams:
         # ~10 us of host time on a path that is host bound; end_step() puts the caller's stream back
         torch.cuda.set_stream(s)
         try:
-            n0 = len(config._pending)
+            config.take_last_entry()
             out = forward_fn()
-            entry = config._pending[-1] if len(config._pending) > n0 else None      # this view's header, if async
+            entry = config.take_last_entry()                 # this view's header entry, if its forward was an async one
             if backward_fn is not None:
                 if self._prev_bwd is not None:
                     s.wait_event(self._prev_bwd)

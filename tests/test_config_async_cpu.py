@@ -197,6 +197,35 @@ def test_recover_policy_marks_the_view_and_neither_warns_nor_counts_a_drop(fake)
     assert config.capacity_for(means, rs) != 0
 
 
+def test_a_forward_is_tied_to_its_own_entry_even_when_it_retires_older_ones(fake):
+    """parallel.ViewStreams asks for the entry of the forward it just issued.  The forward's own capacity_for() polls and
+    retires completed entries, so the LENGTH of the pending list can shrink across a forward that appended one (the round-4
+    bookkeeping compared lengths and lost such a view: its overflow would have gone unnoticed under "recover")."""
+    means, rs = torch.zeros(500, 3), _rs()
+    config.set_async(True, headroom=1.0, warm_calls=1)
+    config.note_forward(means, rs, 1_000, None, 0)
+    with config.overflow_policy("recover"):
+        cap = config.capacity_for(means, rs)
+        config.note_forward(means, rs, -1, _header(900), cap)
+        first = config.take_last_entry()
+        config.note_forward(means, rs, -1, _header(950), cap)
+        second = config.take_last_entry()
+        assert first is not None and second is not None and first is not second
+        assert config.take_last_entry() is None                       # cleared by the call
+        fake.complete(0, 1)                                           # both headers have arrived ...
+        n0 = len(config._pending)
+        cap = config.capacity_for(means, rs)                          # ... so the next forward's poll retires them
+        config.note_forward(means, rs, -1, _header(50_000, overflow=1), cap)
+        assert len(config._pending) < n0 + 1                          # the length went DOWN across a forward that posted
+        third = config.take_last_entry()
+        assert third is config._pending[-1] and third is not second
+        fake.complete(2)
+        config.drain()
+        assert (first[3], second[3], third[3]) == (False, False, True)
+        config.note_forward(means, rs, 1_200, None, 0)                # an exact forward posts nothing
+        assert config.take_last_entry() is None
+
+
 def test_policy_stack_is_per_thread_and_tolerates_an_unbalanced_exit(fake):
     import threading
     seen = {}

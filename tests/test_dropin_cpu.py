@@ -57,6 +57,8 @@ def test_install_replaces_rebinds_falls_through_and_uninstall_restores():
         # l1 of something that is not an RGB image on the device: the reference's own expression
         a, b = torch.rand(1, 8, 8), torch.rand(1, 8, 8)
         assert torch.equal(ls.l1_loss(a, b), torch.abs(a - b).mean())
+        # ssim the shared pass does not cover (another window, host tensors): the function install() replaced answers
+        assert float(ls.ssim(a, b, window_size=7)) == 1.0 and float(ls.ssim(torch.rand(3, 8, 8), torch.rand(3, 8, 8))) == 1.0
         # Adam: parameters on the host -> the reference's optimizer is kept (FusedAdam has no CPU path)
         m = gm.GaussianModel()
         m.training_setup(None)
