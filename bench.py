@@ -268,6 +268,64 @@ def run_leg(wl, api, exact, streams, steps, warmup, world, dev, fused=True):
     return wl.total_views * steps / dt, dt / steps * 1e3, host_ms, step
 
 
+def live_pmc_counters(timeout_s=150):
+    """FETCH_SIZE / WRITE_SIZE per kernel and launch, collected NOW on this box: two rocprofv3 passes (one counter each,
+    --kernel-trace only, from /tmp with TMPDIR=/tmp -- the recipe of MI355X_MICROARCH.md / tools/pmc_run.sh) over a child run of
+    this script on the same workload (4 views, 1 step, no extras).  Returns ({kernel: {counter: mean per launch}}, note); the
+    dict is empty when anything goes wrong (no rocprofv3, a pass that fails or does not end in time) and the caller falls back
+    to the committed counter file."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return {}, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return {}, "this run is itself being profiled"
+    out = tempfile.mkdtemp(prefix="lr_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--views", "4", "--steps", "1", "--warmup", "1", "--no-cpu-baseline",
+             "--no-extras", "--sustain-seconds", "0"]
+    acc = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            cmd = [exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", ctr, "--"] + child
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = p.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)              # the process group this call started, nothing else
+                p.wait()
+                return {}, f"the {ctr} pass did not end within {timeout_s} s"
+            if rc != 0:
+                return {}, f"the {ctr} pass ended with code {rc}"
+            rows = 0
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(path) as f:
+                    for row in csv.DictReader(f):
+                        if row.get("Counter_Name") != ctr:
+                            continue
+                        m = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", row["Kernel_Name"])
+                        a = acc.setdefault(m.group(1) if m else row["Kernel_Name"][:40], {}).setdefault(ctr, [0.0, 0])
+                        a[0] += float(row["Counter_Value"])
+                        a[1] += 1
+                        rows += 1
+            if rows == 0:
+                return {}, f"the {ctr} pass wrote no counter rows"
+    except (OSError, ValueError, KeyError) as e:
+        return {}, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    return ({k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()},
+            "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, one pass each, run by this bench.py on this box "
+            "(child: bench.py --views 4 --steps 1 --warmup 1 --no-extras)")
+
+
 def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     """The same steps again on ONE stream so that kernels do not overlap, with per-stage HIP events recorded on the
     launch stream (each blend / per-Gaussian stage is exactly one kernel launch)."""
@@ -289,25 +347,48 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     b_f, b_b = path_bytes(P, V_mean, R_mean, N, T, K, M)
     b_moved = moved_bytes(P, V_mean, R_mean, N, T, K, M, V)
     per_rank_views_s = value / world
-    # HBM traffic of the dominant kernel: NOT measured in this run (rocprofv3 --pmc needs its own passes).  It is read
-    # from the committed counter file of the same workload and build generation (tools/pmc_run.sh: separate passes for
-    # FETCH_SIZE and WRITE_SIZE, both in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte-per-lane
-    # reads on gfx950); `traffic_source` says which file.
+    # HBM traffic of the dominant kernel (rocprofv3 --pmc needs its own passes, separate from the timed region): at N = 1 on
+    # the default workload the two byte-counter passes are run right here, on this box, over a child run of this script
+    # (live_pmc_counters: FETCH_SIZE and WRITE_SIZE, one pass each, both in KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for 16-byte-per-lane reads on gfx950).  The committed counter file of the same build (tools/pmc_run.sh, more
+    # counters: VALU instructions, clocks) supplies `valu_issue`, and the bytes as well where no live pass ran (N > 1, other
+    # workloads, --no-extras, a run that is itself being profiled); `traffic_source` says which.
     traffic, valu, source, traffic_ratios = None, None, None, None
+    traffic_file, source_file, live, live_note = None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c3.json")
-    if wl.name == "c3" and args.gaussians is None and os.path.exists(pmc_path):
+    default_c3 = wl.name == "c3" and args.gaussians is None and args.views is None and args.resolution is None
+    if default_c3 and world == 1 and not args.no_extras and not args.no_live_pmc and api == "views" and not exact:
+        torch.cuda.synchronize()
+        live = live_pmc_counters()
+        live_note = live[1]
+    if wl.name == "c3" and args.gaussians is None and (os.path.exists(pmc_path) or live):
         try:
-            allpmc = json.load(open(pmc_path))
+            allpmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
             # the counter file is stamped with the lr_version() (a hash of the kernel sources) it was collected on
             # (tools/pmc_run.sh / pmc_summary.py); another build's counters are refused, not quoted
             stamp = allpmc.get("_lr_version")
             if stamp != _lib.lib().lr_version().decode():
                 source = f"stale: profiles/pmc_c3.json was collected on '{stamp}', this build is '{_lib.lib().lr_version().decode()}'"
                 allpmc = {}
-            pmc = next((v for k, v in allpmc.items() if isinstance(v, dict) and k.startswith("k_" + dom)), {})
+            # the kernel of the single-stream stage timing: the 2-wave k_render_bwd<...>, not the TILE shape the multi-stream legs
+            # of the same run launch (k_render_bwd_tile) -- '<' sorts before '_'
+            pick = lambda d: next((d[k] for k in sorted(d) if isinstance(d[k], dict) and k.startswith("k_" + dom)), {})
+            pmc = pick(allpmc)
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
                 source = "committed PMC pass profiles/pmc_c3.json" + (f" ({allpmc['_collected']})" if "_collected" in allpmc else "")
+            # the byte counters again, collected by THIS run on THIS box (two short rocprofv3 passes over a child run); they
+            # replace the committed file's bytes -- which stay in the line as `traffic_committed_file` -- wherever they exist
+            if live is not None:
+                live_note = live[1]
+                for k, v in live[0].items():
+                    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                        allpmc.setdefault(k, {})
+                        allpmc[k] = dict(allpmc[k], FETCH_SIZE=v["FETCH_SIZE"], WRITE_SIZE=v["WRITE_SIZE"])
+                lp = pick(live[0])
+                if "FETCH_SIZE" in lp and "WRITE_SIZE" in lp:
+                    traffic_file, traffic = traffic, int((2.0 * lp["FETCH_SIZE"] + lp["WRITE_SIZE"]) * 1024)
+                    source_file, source = source, "live: " + live[1]
             if "SQ_INSTS_VALU" in pmc:
                 # the blend kernels are VALU bound: wave-instructions per launch from the PMC pass over
                 # this launch's measured duration, against the ARCHITECTURAL issue rate -- a wave64 VALU instruction occupies
@@ -348,7 +429,9 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     moved_view_s = b_moved / max(sum(stages[k][0] for k in stages) / max(V * steps, 1) * 1e-3, 1e-12)
     return {
         "bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source, "valu_issue": valu,
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
+        "traffic_committed_file": traffic_file, "traffic_committed_file_source": source_file,
+        "live_pmc": live_note, "valu_issue": valu,
         "counter_vs_algorithmic_bytes": traffic_ratios,
         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
         "launches": dom_calls,
@@ -377,7 +460,9 @@ def main():
     ap.add_argument("--gaussians", type=int, default=None, help="override the Gaussian count (debug)")
     ap.add_argument("--exact", action="store_true", help="reference-style host sync per view instead of async mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the entry_points / other_workloads legs")
+    ap.add_argument("--no-extras", action="store_true", help="skip the entry_points / other_workloads legs (and the live PMC passes)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not run the two rocprofv3 byte-counter passes; roofline.traffic then comes from profiles/pmc_c3.json")
     ap.add_argument("--resolution", default=None, help="WxH override (the metric uses 1920x1080)")
     ap.add_argument("--sh-degree", type=int, default=3, choices=[0, 1, 2, 3], help="active SH degree (diagnostics; the metric uses 3)")
     ap.add_argument("--api", default="views", choices=["views", "autograd", "views-loss"],
