@@ -268,15 +268,39 @@ def run_leg(wl, api, exact, streams, steps, warmup, world, dev, fused=True):
     return wl.total_views * steps / dt, dt / steps * 1e3, host_ms, step
 
 
-def live_pmc_counters(timeout_s=150):
+def read_counter_csv(directory, counter, acc):
+    """Add the rows of `counter` in rocprofv3's *counter_collection.csv files under `directory` to acc[kernel][counter] =
+    [sum, launches] (kernel = the k_name<...> part of the mangled name, as tools/pmc_summary.py shortens it).  Returns the
+    number of rows read."""
+    import csv
+    import glob
+    import re
+    rows = 0
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if row.get("Counter_Name") != counter:
+                    continue
+                m = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", row["Kernel_Name"])
+                a = acc.setdefault(m.group(1) if m else row["Kernel_Name"][:40], {}).setdefault(counter, [0.0, 0])
+                a[0] += float(row["Counter_Value"])
+                a[1] += 1
+                rows += 1
+    return rows
+
+
+def pick_kernel(counters, stage):
+    """The counter record of the kernel a single-stream stage timing belongs to: k_<stage><...> before k_<stage>_other (the
+    2-wave k_render_bwd<...>, not k_render_bwd_tile, which only the multi-stream legs launch) -- '<' sorts before '_'."""
+    return next((counters[k] for k in sorted(counters) if isinstance(counters[k], dict) and k.startswith("k_" + stage)), {})
+
+
+def live_pmc_counters(timeout_s=90):
     """FETCH_SIZE / WRITE_SIZE per kernel and launch, collected NOW on this box: two rocprofv3 passes (one counter each,
     --kernel-trace only, from /tmp with TMPDIR=/tmp -- the recipe of MI355X_MICROARCH.md / tools/pmc_run.sh) over a child run of
     this script on the same workload (4 views, 1 step, no extras).  Returns ({kernel: {counter: mean per launch}}, note); the
     dict is empty when anything goes wrong (no rocprofv3, a pass that fails or does not end in time) and the caller falls back
     to the committed counter file."""
-    import csv
-    import glob
-    import re
     import shutil
     import signal
     import subprocess
@@ -304,18 +328,7 @@ def live_pmc_counters(timeout_s=150):
                 return {}, f"the {ctr} pass did not end within {timeout_s} s"
             if rc != 0:
                 return {}, f"the {ctr} pass ended with code {rc}"
-            rows = 0
-            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                with open(path) as f:
-                    for row in csv.DictReader(f):
-                        if row.get("Counter_Name") != ctr:
-                            continue
-                        m = re.search(r"(k_[A-Za-z0-9_]+(?:<[^>]*>)?)", row["Kernel_Name"])
-                        a = acc.setdefault(m.group(1) if m else row["Kernel_Name"][:40], {}).setdefault(ctr, [0.0, 0])
-                        a[0] += float(row["Counter_Value"])
-                        a[1] += 1
-                        rows += 1
-            if rows == 0:
+            if read_counter_csv(d, ctr, acc) == 0:
                 return {}, f"the {ctr} pass wrote no counter rows"
     except (OSError, ValueError, KeyError) as e:
         return {}, f"{type(e).__name__}: {e}"
@@ -372,8 +385,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
                 allpmc = {}
             # the kernel of the single-stream stage timing: the 2-wave k_render_bwd<...>, not the TILE shape the multi-stream legs
             # of the same run launch (k_render_bwd_tile) -- '<' sorts before '_'
-            pick = lambda d: next((d[k] for k in sorted(d) if isinstance(d[k], dict) and k.startswith("k_" + dom)), {})
-            pmc = pick(allpmc)
+            pmc = pick_kernel(allpmc, dom)
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
                 source = "committed PMC pass profiles/pmc_c3.json" + (f" ({allpmc['_collected']})" if "_collected" in allpmc else "")
@@ -385,7 +397,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
                     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                         allpmc.setdefault(k, {})
                         allpmc[k] = dict(allpmc[k], FETCH_SIZE=v["FETCH_SIZE"], WRITE_SIZE=v["WRITE_SIZE"])
-                lp = pick(live[0])
+                lp = pick_kernel(live[0], dom)
                 if "FETCH_SIZE" in lp and "WRITE_SIZE" in lp:
                     traffic_file, traffic = traffic, int((2.0 * lp["FETCH_SIZE"] + lp["WRITE_SIZE"]) * 1024)
                     source_file, source = source, "live: " + live[1]

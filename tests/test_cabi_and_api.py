@@ -189,3 +189,27 @@ def test_division_free_index_arithmetic_of_the_binning_is_exact():
                     assert (hi << lk) + lo == (c // j) * k + (c % j)
                 else:
                     assert (hi << (lj + 1)) + lo == (c // j) * (j << 1) + (c % j)
+
+
+def test_bench_reads_rocprofv3_counter_files_and_picks_the_timed_kernel(tmp_path):
+    """bench.py's live byte-counter leg: the csv rocprofv3 --pmc writes (one row per dispatch and counter) averaged per kernel and
+    launch, and the record of the kernel the single-stream stage timing belongs to (the 2-wave k_render_bwd<...>, not the TILE
+    shape's k_render_bwd_tile that the multi-stream legs of the same run launch)."""
+    import bench
+    d = tmp_path / "FETCH_SIZE" / "box"
+    d.mkdir(parents=True)
+    head = "Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value,Start_Timestamp,End_Timestamp\n"
+    rows = [(1, "void lr::(anonymous namespace)::k_render_bwd_tile(int, int) [clone .kd]", "FETCH_SIZE", 50000.0),
+            (2, "void lr::(anonymous namespace)::k_render_bwd<false, true, false>(int, int)", "FETCH_SIZE", 30000.0),
+            (3, "void lr::(anonymous namespace)::k_render_bwd<false, true, false>(int, int)", "FETCH_SIZE", 34000.0),
+            (3, "void lr::(anonymous namespace)::k_render_bwd<false, true, false>(int, int)", "SQ_WAVES", 7.0),
+            (4, "__amd_rocclr_copyBuffer", "FETCH_SIZE", 1.0)]
+    (d / "123_FETCH_SIZE_counter_collection.csv").write_text(
+        head + "".join(f'{i},{i},0,"{k}",{c},{v},0,10\n' for i, k, c, v in rows))
+    acc = {}
+    assert bench.read_counter_csv(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", acc) == 4          # the SQ_WAVES row is not this pass's
+    assert acc["k_render_bwd<false, true, false>"]["FETCH_SIZE"] == [64000.0, 2] and acc["k_render_bwd_tile"]["FETCH_SIZE"] == [50000.0, 1]
+    mean = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
+    assert bench.pick_kernel(mean, "render_bwd") == {"FETCH_SIZE": 32000.0}
+    assert bench.pick_kernel(mean, "gauss_bwd") == {}
+    assert bench.read_counter_csv(str(tmp_path / "nothing_here"), "FETCH_SIZE", {}) == 0
