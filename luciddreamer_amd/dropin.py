@@ -15,7 +15,9 @@ What is replaced (each one individually switchable; `uninstall(handle)` puts eve
   Adam                   GaussianModel.training_setup (scene/gaussian_model.py:152-165) keeps building its six groups; the
                          torch.optim.Adam it ends with is replaced by optim.FusedAdam over the same groups (one launch per step).
   densification stats    GaussianModel.add_densification_stats (:405-407) -> lr_densify_stats (one kernel, no boolean-mask
-                         indexing, no host round trip); the visibility filter returned by the replaced render carries the radii.
+                         indexing, no host round trip); the visibility filter returned by the replaced render carries the radii
+                         -- and keeps the loop's own `max_radii2D[filter] = torch.max(max_radii2D[filter], radii[filter])`
+                         (R/luciddreamer.py:310-312) on the device: three host round trips per iteration less.
   densify / prune / ply  densify.patch(cls): prune_points, densification_postfix, densify_and_clone / _split / _and_prune,
                          save_ply / load_ply over the library's row store.
 
@@ -52,6 +54,108 @@ def _rebind(handle, original, replacement, skip):
                 handle.set(mod, k, replacement)
 
 
+# ---- the visibility filter of the replaced render ---------------------------------------------------------------------------
+# The caller's loop keeps `max_radii2D[visibility_filter] = torch.max(max_radii2D[visibility_filter], radii[visibility_filter])`
+# (R/luciddreamer.py:310-312) in its own body: three boolean-mask indexings, each a nonzero() with a device -> host read of
+# the row count -- the host stops until the iteration's whole GPU work has drained, three times per iteration (~1 ms of a
+# 2.3 ms iteration at 1 M Gaussians / 512^2).  The filter this module's render returns is a bool tensor SUBCLASS: indexing a
+# plain tensor with it yields a lazy row selection, torch.max / torch.maximum of two such selections stays lazy, and assigning
+# the result through the same filter runs as ONE dense torch.where on the device -- same values, no row count, no host read.
+# Anything else done with a lazy selection (arithmetic, in-place ops, .shape, printing ...) materialises it first and is the
+# plain operation; a filter used in any other way behaves as the bool tensor it is.
+lazy_assignments = 0          # masked assignments that ran without a host read (tests, diagnostics)
+
+
+def _materialise(x):
+    if isinstance(x, _Rows):
+        return x.rows()
+    if isinstance(x, _VisFilter):
+        return x.as_subclass(torch.Tensor)
+    if isinstance(x, (tuple, list)):
+        return type(x)(_materialise(v) for v in x)
+    if isinstance(x, dict):
+        return {k: _materialise(v) for k, v in x.items()}
+    return x
+
+
+def _filter_function(func, args, kwargs):
+    global lazy_assignments
+    kwargs = kwargs or {}
+    if not kwargs:
+        if func is torch.Tensor.__getitem__ and len(args) == 2 and isinstance(args[1], _VisFilter) and _Rows.can_select(args[0], args[1]):
+            return _Rows.make("rows", args[1], args[0])
+        if func in (torch.max, torch.maximum) and len(args) == 2 and all(isinstance(a, _Rows) for a in args) and args[0].mask is args[1].mask:
+            return _Rows.make("max", args[0].mask, args[0], args[1])
+        if func is torch.Tensor.__setitem__ and len(args) == 3 and isinstance(args[1], _VisFilter) and isinstance(args[2], _Rows) \
+                and args[2].mask is args[1] and _Rows.can_select(args[0], args[1]):
+            dest, m = args[0], args[1].as_subclass(torch.Tensor)
+            with torch._C.DisableTorchFunction():
+                dense = args[2].dense()
+                if dense.shape == dest.shape:
+                    dest.copy_(torch.where(m.view(-1, *([1] * (dest.dim() - 1))), dense.to(dest.dtype), dest))
+                    lazy_assignments += 1
+                    return None
+    with torch._C.DisableTorchFunction():
+        return func(*_materialise(tuple(args)), **_materialise(kwargs))
+
+
+class _Rows(torch.Tensor):
+    """`base[filter]` (or the elementwise max of two of them) not yet evaluated: see above."""
+
+    @staticmethod
+    def can_select(base, mask):
+        return (type(base) is torch.Tensor and mask.dim() == 1 and base.dim() >= 1 and base.shape[0] == mask.shape[0]
+                and base.device == mask.device and not (base.requires_grad and torch.is_grad_enabled()))
+
+    @staticmethod
+    def make(kind, mask, *operands):
+        with torch._C.DisableTorchFunction():
+            r = torch.empty(0, device=mask.device).as_subclass(_Rows)
+        r.kind, r.mask, r.operands = kind, mask, operands
+        r.versions = (mask._version,) + tuple(o._version for o in operands if kind == "rows")
+        return r
+
+    def dense(self):
+        """The full-length tensor whose rows under the filter are this selection."""
+        if self.kind == "rows":
+            # eager indexing would have copied the rows when the selection was written down; a selection that is only
+            # evaluated now must find its source as it was then -- anything else is refused, loudly
+            if (self.mask._version, self.operands[0]._version) != self.versions:
+                raise RuntimeError("luciddreamer_amd: a tensor indexed with the visibility filter of the installed render() was "
+                                   "changed in place before the selection was used; take the selection with .clone() or "
+                                   "install(..., lazy_filter=False)")
+            return self.operands[0]
+        return torch.maximum(self.operands[0].dense(), self.operands[1].dense())
+
+    def rows(self):
+        with torch._C.DisableTorchFunction():
+            return self.dense()[self.mask.as_subclass(torch.Tensor)]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return _filter_function(func, args, kwargs)
+
+    def __reduce_ex__(self, proto):
+        return self.rows().__reduce_ex__(proto)
+
+
+class _VisFilter(torch.Tensor):
+    """The bool visibility filter (radii > 0) returned by the replaced render; carries the radii for the fused statistics."""
+
+    @staticmethod
+    def wrap(mask, radii):
+        f = mask.as_subclass(_VisFilter)
+        f._lr_radii = radii
+        return f
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        return _filter_function(func, args, kwargs)
+
+    def __reduce_ex__(self, proto):
+        return self.as_subclass(torch.Tensor).__reduce_ex__(proto)
+
+
 _STORED = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
 
 
@@ -66,9 +170,10 @@ def _raw_ok(pc, opt, override_color):
 
 
 def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=True, losses=True, adam=True, stats=True,
-            densify=True, rebind=True):
+            densify=True, rebind=True, lazy_filter=True):
     """gaussian_renderer, loss: the reference's modules (or None to leave alone); gaussian_model: its GaussianModel class or
-    the module that defines it.  A single namespace with attributes `gaussian_renderer`, `loss`, `gaussian_model` (what
+    the module that defines it.  lazy_filter: the visibility filter the replaced render returns keeps the caller's masked
+    max-radii update on the device (_VisFilter above); False = a plain bool tensor.  A single namespace with attributes `gaussian_renderer`, `loss`, `gaussian_model` (what
     oracle/ref_python.reference_modules yields) may be passed as the first argument.  Returns a handle for uninstall()."""
     if gaussian_renderer is not None and loss is None and gaussian_model is None and hasattr(gaussian_renderer, "gaussian_renderer"):
         ns = gaussian_renderer
@@ -87,7 +192,12 @@ def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=Tr
                 return orig_render(viewpoint_camera, pc, opt, bg_color, scaling_modifier, override_color, render_only)
             out = gr.render_raw(viewpoint_camera, pc, opt, bg_color, scaling_modifier, render_only)
             if not render_only:
-                out["visibility_filter"]._lr_radii = out["radii"]        # for the fused densification statistics below
+                # carries the radii for the fused densification statistics below, and keeps the caller's own
+                # `max_radii2D[filter] = torch.max(max_radii2D[filter], radii[filter])` on the device (_VisFilter above)
+                if lazy_filter:
+                    out["visibility_filter"] = _VisFilter.wrap(out["visibility_filter"], out["radii"])
+                else:
+                    out["visibility_filter"]._lr_radii = out["radii"]
             return out
         render_.__wrapped__ = orig_render
         h.set(gaussian_renderer, "render", render_)

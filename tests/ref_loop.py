@@ -70,11 +70,26 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
                 gm.densify_and_prune(opt.densify_grad_threshold, 0.005, extent, None)
             gm.optimizer.step()                                                    # :325-327
             gm.optimizer.zero_grad(set_to_none=True)
-        losses.append(float(loss.detach()))
+        # the reference's loop does not read the loss (R/luciddreamer.py:283-327 has no .item()): the values are kept on the
+        # device and fetched after the last iteration, so that the harness adds no host <-> device round trip of its own
+        losses.append(loss.detach())
         counts.append(int(gm.get_xyz.shape[0]))
         if on_iteration is not None:
             on_iteration(iteration, gm, pkg, loss)
-    return dict(loss=np.array(losses), P=np.array(counts))
+    return dict(loss=np.array([float(v) for v in losses]), P=np.array(counts))
+
+
+def resident(R, gm, device, cams, targets, depth_targets=None, iters=200, opt=None):
+    """What the reference has in place BEFORE its loop starts, so that a timed train() is iterations only: cameras and target
+    images on the device (R/scene/cameras.py keeps original_image on data_device = cuda) and the optimizer built
+    (GaussianModel.training_setup is called once, before the loop: R/luciddreamer.py:279).  Returns (cams, targets, depths, opt)
+    to pass to train()."""
+    opt = opt or R.arguments.GSParams()
+    opt.iterations = iters + 1
+    if gm.optimizer is None:
+        gm.training_setup(opt)
+    return ([c.to(device) for c in cams], [t.to(device) for t in targets],
+            None if depth_targets is None else [t.to(device) for t in depth_targets], opt)
 
 
 @contextlib.contextmanager

@@ -24,9 +24,10 @@ def main():
     for be in ("ours", "refdev", "ours", "refdev"):
         with ref_loop.stack(be) as (R, dev):
             gm = ref_loop.model_from_cloud(R, base, dev)
+            cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)
             torch.cuda.synchronize()
             t0 = time.time()
-            out = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+            out = ref_loop.train(R, gm, dev, cams_r, order, tg_r, dg_r, iters=iters, opt=opt_r)
             torch.cuda.synchronize()
             print(f"{be}: {iters} iterations in {time.time() - t0:.2f}s ({(time.time() - t0) / iters * 1e3:.2f} ms/iteration), "
                   f"final loss {out['loss'][-1]:.5f}")

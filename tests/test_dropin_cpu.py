@@ -4,6 +4,7 @@ pieces themselves run on the GPU (tests/test_gpu_reference_stack.py::test_instal
 import sys
 import types
 
+import pytest
 import torch
 
 import luciddreamer_amd
@@ -88,3 +89,54 @@ def test_install_takes_a_namespace_and_switches_individually():
     finally:
         for m in (gr, ls, gm, caller):
             sys.modules.pop(m.__name__, None)
+
+
+def test_visibility_filter_keeps_the_masked_max_radii_update_on_the_device_and_is_a_plain_mask_otherwise():
+    """The filter the installed render() returns (dropin._VisFilter): the loop's own
+    `max_radii2D[f] = torch.max(max_radii2D[f], radii[f])` (R/luciddreamer.py:310-312) runs as one dense where() -- no nonzero, no
+    host read -- with the values of the eager statement; every other use of the filter or of a selection taken with it is the
+    plain operation (the reference's own add_densification_stats body, arithmetic, scalars, pickling)."""
+    import pickle
+    from luciddreamer_amd import dropin
+    torch.manual_seed(0)
+    P = 257
+    radii = torch.randint(0, 20, (P,), dtype=torch.int32)
+    mask = radii > 5
+    f = dropin._VisFilter.wrap(mask.clone(), radii)
+    mr = torch.rand(P) * 10
+    want, got = mr.clone(), mr.clone()
+    want[mask] = torch.max(want[mask], radii[mask])
+    n0 = dropin.lazy_assignments
+    got[f] = torch.max(got[f], radii[f])
+    assert torch.equal(want, got) and dropin.lazy_assignments == n0 + 1 and got.dtype == torch.float32
+    # [P, 1] destination, torch.maximum spelling
+    d_want, d_got, ones = torch.zeros(P, 1), torch.zeros(P, 1), torch.rand(P, 1)
+    d_want[mask] = torch.maximum(d_want[mask], ones[mask])
+    d_got[f] = torch.maximum(d_got[f], ones[f])
+    assert torch.equal(d_want, d_got) and dropin.lazy_assignments == n0 + 2
+    # the reference's own statistics body (scene/gaussian_model.py:405-407): getitem, in-place add, setitem; tuple index
+    acc_want, acc_got, g = torch.zeros(P, 1), torch.zeros(P, 1), torch.rand(P, 3)
+    acc_want[mask] += torch.norm(g[mask, :2], dim=-1, keepdim=True)
+    acc_got[f] += torch.norm(g[f, :2], dim=-1, keepdim=True)
+    assert torch.equal(acc_want, acc_got)
+    # a selection used in any other way is the eager selection
+    sel = mr[f]
+    assert sel.shape == mr[mask].shape and torch.equal(sel * 2, mr[mask] * 2) and float(sel.sum()) == float(mr[mask].sum())
+    assert type(sel * 2) is torch.Tensor and torch.equal(torch.max(mr[f], mr[mask]), mr[mask])
+    x, y = mr.clone(), mr.clone()
+    x[f] = 5.0
+    y[mask] = 5.0
+    assert torch.equal(x, y)
+    x[f] = mr[f] * 2
+    y[mask] = mr[mask] * 2
+    assert torch.equal(x, y)
+    # the filter itself: a bool tensor in every other respect, and it pickles as one
+    assert int(f.sum()) == int(mask.sum()) and type(~f) is torch.Tensor and torch.equal(~f, ~mask)
+    back = pickle.loads(pickle.dumps(f))
+    assert type(back) is torch.Tensor and torch.equal(back, mask)
+    # a selection that outlives an in-place change of its source is refused, not silently different from eager indexing
+    src = mr.clone()
+    held = src[f]
+    src.add_(1.0)
+    with pytest.raises(RuntimeError, match="changed in place"):
+        held.sum()

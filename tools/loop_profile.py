@@ -30,12 +30,13 @@ with ref_loop.stack("ours") as (R, dev):
     try:
         for rnd in range(2):
             gm = ref_loop.model_from_cloud(R, base, dev)
+            cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)
             torch.cuda.synchronize()
             pr = cProfile.Profile()
             t0 = time.perf_counter()
             if rnd:
                 pr.enable()
-            ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+            ref_loop.train(R, gm, dev, cams_r, order, tg_r, dg_r, iters=iters, opt=opt_r)
             if rnd:
                 pr.disable()
             torch.cuda.synchronize()
@@ -44,4 +45,6 @@ with ref_loop.stack("ours") as (R, dev):
         luciddreamer_amd.uninstall(h)
 out = io.StringIO()
 pstats.Stats(pr, stream=out).sort_stats("tottime").print_stats(28)
-print(out.getvalue()[:5000])
+print(out.getvalue()[:6000])
+from luciddreamer_amd import dropin
+print("lazy assignments:", dropin.lazy_assignments)

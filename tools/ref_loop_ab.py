@@ -35,12 +35,13 @@ def main():
             config.reset()
             setup()
             with ref_loop.stack("ours") as (R, dev):
-                handle = luciddreamer_amd.install(R) if name.endswith("+install") else None
+                handle = luciddreamer_amd.install(R, lazy_filter=not os.environ.get("LR_NO_LAZY_FILTER")) if name.endswith("+install") else None
                 try:
                     gm = ref_loop.model_from_cloud(R, base, dev)
+                    cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    out = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
+                    out = ref_loop.train(R, gm, dev, cams_r, order, tg_r, dg_r, iters=iters, opt=opt_r)
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - t0
                 finally:
