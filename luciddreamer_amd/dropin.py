@@ -92,7 +92,9 @@ def _filter_function(func, args, kwargs):
             with torch._C.DisableTorchFunction():
                 dense = args[2].dense()
                 if dense.shape == dest.shape:
-                    dest.copy_(torch.where(m.view(-1, *([1] * (dest.dim() - 1))), dense.to(dest.dtype), dest))
+                    if dest.dim() > 1:
+                        m = m.view(-1, *([1] * (dest.dim() - 1)))
+                    torch.where(m, dense if dense.dtype == dest.dtype else dense.to(dest.dtype), dest, out=dest)
                     lazy_assignments += 1
                     return None
     with torch._C.DisableTorchFunction():
@@ -107,10 +109,15 @@ class _Rows(torch.Tensor):
         return (type(base) is torch.Tensor and mask.dim() == 1 and base.dim() >= 1 and base.shape[0] == mask.shape[0]
                 and base.device == mask.device and not (base.requires_grad and torch.is_grad_enabled()))
 
+    _empty = {}                     # one zero-size tensor per device: a selection object is a fresh VIEW of it, no allocation
+
     @staticmethod
     def make(kind, mask, *operands):
         with torch._C.DisableTorchFunction():
-            r = torch.empty(0, device=mask.device).as_subclass(_Rows)
+            e = _Rows._empty.get(mask.device)
+            if e is None:
+                e = _Rows._empty[mask.device] = torch.empty(0, device=mask.device)
+            r = e.as_subclass(_Rows)
         r.kind, r.mask, r.operands = kind, mask, operands
         r.versions = (mask._version,) + tuple(o._version for o in operands if kind == "rows")
         return r
