@@ -341,7 +341,7 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
 // nullptr -- the kernel leaves the header there behind `log_tag` (lr_header_poll on a log ticket spins on the tag).
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
-                    uint32_t log_tag, hipStream_t s);
+                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, hipStream_t s);
 // optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
 struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };
 // count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1
@@ -354,7 +354,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_PART_SCAN, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): BLEND_QUAD = 4 waves per

@@ -19,7 +19,13 @@
 //                                        histogram the hits over the partition bins in LDS (one bin per tile up to 16384
 //                                        tiles; 2^s neighbouring tiles per bin beyond that).  Integer LDS atomics: counts
 //                                        are order-free.
-//   k_part_scan1                         per-bin prefix over the workgroups (+ bin totals).
+//                                        Each workgroup then reserves its range inside every bin it found entries for with
+//                                        ONE returning atomic per (workgroup, non-empty bin) on the bin's cursor -- zeroed by
+//                                        the scan kernel before it, holding the bin's total after it.  (Rounds 2-4 wrote
+//                                        per-workgroup counts and ran a kernel, k_part_scan1, over them: a launch and 4.9 us
+//                                        for what the count kernel's tail does in ~3; lr_tune_set("part_scan", 1) still
+//                                        selects it.  Which workgroup gets which range now depends on arrival -- and does
+//                                        not matter, see the sort below.)
 //   k_part<SCATTER>                      every workgroup first scans the bin totals itself (bin start; workgroup 0 also
 //                                        publishes the per-tile ranges: no identifyTileRanges pass, no memset); then
 //                                        the same walk again; every hit takes the next free position of its bin from
@@ -33,8 +39,9 @@
 //                                        Gaussian index -- so the result is exactly the reference's list, bit-for-bit
 //                                        repeatable, whatever order the scatter produced.
 //
-// 7 launches instead of 21, no global depth sort (the depth order is only ever needed inside a tile), no global
-// atomics, nothing that depends on a host round trip: every kernel takes its counts from the device-side header.
+// 6 launches instead of 21 (7 for the whole forward), no global depth sort (the depth order is only ever needed inside a tile), no global
+// atomics per instance (one per workgroup and bin), nothing that depends on a host round trip: every kernel takes its counts
+// from the device-side header.
 #include <mutex>
 #include "common.h"
 
@@ -67,9 +74,11 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
                 uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, GeomHeader* hdr, uint32_t capacity,
-                uint32_t* __restrict__ log_slot, uint32_t log_tag)
+                uint32_t* __restrict__ log_slot, uint32_t log_tag, uint32_t* __restrict__ zero_words, uint32_t n_zero)
 {
     __shared__ uint32_t s_tmp[4];
+    // the per-bin cursors of the partition (k_part<0> reserves its ranges on them with atomics): zero before its launch
+    for (uint32_t i = blockIdx.x * SCAN_THREADS + threadIdx.x; i < n_zero; i += gridDim.x * SCAN_THREADS) zero_words[i] = 0u;
     __shared__ uint32_t s_wc[4], s_wi[4];
     const bool last_block = blockIdx.x == gridDim.x - 1;
     uint32_t pre_c = 0, pre_i = 0, ref_total = 0;
@@ -355,9 +364,9 @@ template <int MODE>
 __global__ void __launch_bounds__(PART_THREADS)
 k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, const uint32_t* __restrict__ vis_list,
        const uint32_t* __restrict__ offsets, const uint4* __restrict__ hitrec, const GaussRec* __restrict__ rec, const int* __restrict__ radii, const GeomHeader* __restrict__ hdr,
-       uint32_t* __restrict__ part_hist, const uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
+       uint32_t* __restrict__ part_hist, uint32_t* __restrict__ bin_total, uint32_t* __restrict__ bin_start,
        uint2* __restrict__ ranges, uint32_t* __restrict__ big_queue, uint32_t* __restrict__ inst_gid,
-       unsigned long long* __restrict__ words, uint32_t* __restrict__ clear_words, uint32_t n_clear)
+       unsigned long long* __restrict__ words, uint32_t* __restrict__ clear_words, uint32_t n_clear, int reserve)
 {
     extern __shared__ uint32_t s_bin[];                  // [bins + bins / 16 + 1], indexed through bin_slot()
     // the forward's chunk sums (library scratch) have been consumed by k_compact_write: zero for the next forward on this stream
@@ -384,7 +393,18 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
                        if (slot < cap) { atomicAdd(&s_bin[bin_slot((int)(tile >> sub_shift))], 1u); inst_gid[slot] = gid; }
                    });
         lds_barrier();
-        for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[bin_slot(i)];
+        if (reserve) {
+            // this workgroup's range inside every bin it found entries for: ONE returning atomic per (workgroup, non-empty
+            // bin) on the bin's cursor (zeroed by the scan kernel), which ends up holding the bin's total.  Which workgroup
+            // gets which range depends on arrival -- and does not matter: the order inside a bin is made by the per-bin sort,
+            // a total order on the words.  No scan over the workgroups' rows, no launch for it (k_part_scan1: 4.9 us + a gap)
+            for (int i = threadIdx.x; i < bins; i += PART_THREADS) {
+                const uint32_t c = s_bin[bin_slot(i)];
+                row[i] = c != 0u ? atomicAdd(&bin_total[i], c) : 0u;
+            }
+        } else {
+            for (int i = threadIdx.x; i < bins; i += PART_THREADS) row[i] = s_bin[bin_slot(i)];
+        }
     } else {
         walk_chunk(beg, end, gx, gy, own_max, vis_list, offsets, hitrec, rec, radii,
                    [&](uint32_t tile, uint32_t slot, uint32_t, uint32_t dbits) {
@@ -701,11 +721,11 @@ PartPlan part_plan(int num_tiles)
 
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
-                    uint32_t log_tag, hipStream_t s)
+                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
-                       offsets, hdr, capacity, log_slot, log_tag);
+                       offsets, hdr, capacity, log_slot, log_tag, zero_words, n_zero);
 }
 
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
@@ -744,17 +764,21 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     const size_t lds = ((size_t)pp.bins + pp.bins / 16 + 1) * 4;
     // instances of one Gaussian walked by its own lane before the wave shares them (lr_tune_set("walk_own", n))
     const int own_max = tune_get(TUNE_WALK_OWN) >= 0 ? tune_get(TUNE_WALK_OWN) : 12;
+    // lr_tune_set("part_scan", 1): the count kernel leaves per-workgroup counts and k_part_scan1 turns them into bases (rounds
+    // 2-4; A/B partner); default: the count kernel reserves its ranges itself (bin_total arrives zeroed from the scan kernel)
+    const int reserve = tune_get(TUNE_PART_SCAN) == 1 ? 0 : 1;
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
-                       inst_gid, words, clear_words, n_clear);
+                       inst_gid, words, clear_words, n_clear, reserve);
     if (t) t->mark(1, s);
-    hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
-                       part_hist, bin_total);
+    if (!reserve)
+        hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
+                           part_hist, bin_total);
     if (t) t->mark(2, s);
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
-                       inst_gid, words, nullptr, 0u);
+                       inst_gid, words, nullptr, 0u, reserve);
     if (t) t->mark(3, s);
     const int groups4 = (pp.bins + 3) / 4;
     const int part_b = pp.bins < TSORT_CLASS_BLOCKS ? pp.bins : TSORT_CLASS_BLOCKS;

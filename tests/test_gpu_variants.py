@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan"):
         _lib.tune_set(k, -1)
 
 
@@ -272,3 +272,27 @@ def test_mid_size_bins_bucket_sort_and_network_give_the_same_lists(hip_device):
             assert np.array_equal(a["grads"][k], b["grads"][k]), k
     ref = hp.run_oracle(cloud, cam, 3, torch.zeros(3))
     hp.compare_forward(a, ref, max_fragile=max(8, 1e-3 * 480 * 272))
+
+
+@pytest.mark.parametrize("kind,P,W,H,scale_mult", [("band", 60_000, 640, 360, 1.0), ("box", 30_000, 480, 272, 3.0),
+                                                   ("box", 200_000, 512, 512, 1.0), ("box", 4000, 2560, 1440, 6.0)])
+def test_ranges_reserved_by_the_count_kernel_give_the_lists_of_the_scanned_rows(hip_device, kind, P, W, H, scale_mult):
+    """Default: every workgroup of the count kernel reserves its range inside a bin with one returning atomic on the bin's
+    cursor -- which workgroup gets which range depends on arrival; lr_tune_set("part_scan", 1): per-workgroup counts and a scan
+    kernel (rounds 2-4), ranges in workgroup order.  The per-bin sort is a total order on the words, so lists, images and
+    gradients must be the same bits either way -- also run to run (several passes: arrival order differs)."""
+    cloud = synthetic.make_cloud(P, kind, 11)
+    if scale_mult != 1.0:
+        cloud["scales"] = cloud["scales"] * scale_mult
+    cam = cameras.rotate360_path(W, H, n_views=30)[3] if kind == "band" else cameras.identity_camera(W, H)
+    g = synthetic.upstream_grad(H, W)
+    outs = []
+    for v in (1, -1, -1, -1):
+        _lib.tune_set("part_scan", v)
+        outs.append(_run(cloud, cam, hip_device, g))
+    a = outs[0]
+    for b in outs[1:]:
+        assert np.array_equal(a["radii"], b["radii"])
+        assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+        for k in a["grads"]:
+            assert np.array_equal(a["grads"][k], b["grads"][k]), k
