@@ -771,11 +771,12 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words, clear_words, n_clear, reserve);
-    if (t) t->mark(1, s);
-    if (!reserve)
+    if (!reserve) {
+        if (t) t->mark(1, s);
         hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
                            part_hist, bin_total);
-    if (t) t->mark(2, s);
+    }
+    if (t) t->mark(2, s);                                   // closes the stage that is open, opens the scatter's
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words, nullptr, 0u, reserve);
