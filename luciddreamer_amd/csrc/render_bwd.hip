@@ -215,7 +215,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     const int pxA = x0 + (l & 7), pxB = pxA + 8, py = y0 + (l >> 3);
     const bool insA = pxA < W && py < H, insB = !QUAD && pxB < W && py < H;
     const float pyf = (float)py;
-    const float bx0 = (float)x0, bx1 = (float)(x0 + 15), by0 = (float)y0, by1 = (float)(y0 + 7);
     const size_t pixA = (size_t)py * W + pxA, pixB = pixA + 8;
     const size_t N = (size_t)W * H;
 

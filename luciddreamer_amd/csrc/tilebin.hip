@@ -681,7 +681,7 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
     __shared__ unsigned long long s_red[2 * (TSORT_THREADS / 64)];
     __shared__ uint32_t s_wave[TSORT_THREADS / 64];
     __shared__ uint32_t s_bad;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x;
     const uint32_t count = big_queue[0];
     for (uint32_t qi = blockIdx.x; qi < count; qi += gridDim.x) {
     const int bin = (int)big_queue[1 + qi];
@@ -791,9 +791,13 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     // the large bins: LDS for the bucket sort (32 KB of words; three workgroups per CU) unless the AVERAGE bin is already
     // beyond it -- then 128 KB, so that bins of up to 16384 entries are sorted in LDS (a hint for speed only: a bin that
     // does not fit this launch's LDS is sorted in place in global memory).  Capped grid: a sparse view queues nothing
-    const bool huge = bin_bound_hint / (long long)pp.bins > (long long)TSORT_MID_LDS;
+    const long long avg_bin = bin_bound_hint / (long long)pp.bins;
+    const bool huge = avg_bin > (long long)TSORT_MID_LDS;
     const uint32_t lds_entries = huge ? (uint32_t)TSORT_BIG_LDS : (uint32_t)TSORT_MID_LDS;
-    const int large_cap = huge ? TSORT_BIG_BLOCKS : TSORT_LARGE_BLOCKS;        // what is resident at once; the queue is strided
+    // what is resident at once (the queue is strided) -- or, where the AVERAGE bin is far below the queue's threshold (a C3
+    // view: 70 entries per tile, the queue almost always empty), a small grid: what a launch costs that finds nothing to do
+    // is its workgroups (768: 4.4 us, 64: the launch floor).  A hint for speed only, like `huge`
+    const int large_cap = huge ? TSORT_BIG_BLOCKS : (avg_bin <= (long long)TSORT_LDS ? TSORT_LARGE_BLOCKS / 12 : TSORT_LARGE_BLOCKS);
     const int large_blocks = pp.bins < large_cap ? pp.bins : large_cap;
     hipLaunchKernelGGL(k_tile_sort_large, dim3(large_blocks), dim3(TSORT_THREADS), (size_t)lds_entries * 8, s, pp.sub_shift,
                        slot_bits, num_tiles, lds_entries, bin_start, bin_total, words, point_list, ranges, big_queue);
