@@ -91,9 +91,15 @@ def test_install_switches_the_unchanged_loop_onto_the_fused_pieces(hip_device):
             h = luciddreamer_amd.install(R) if mode == "installed" else None
             try:
                 gm = ref_loop.model_from_cloud(R, base, dev)
+                from luciddreamer_amd import dropin
+                lazy0 = dropin.lazy_assignments
                 res = ref_loop.train(R, gm, dev, cams, order, targets, depths, iters=iters)
                 if h is not None:
                     assert isinstance(gm.optimizer, FusedAdam) and R.gaussian_renderer.render is not before[0]
+                    # the loop's own `max_radii2D[filter] = torch.max(...)` line stayed on the device in every iteration
+                    assert dropin.lazy_assignments == lazy0 + iters
+                else:
+                    assert dropin.lazy_assignments == lazy0
                 res["accum"] = gm.xyz_gradient_accum.detach().cpu().numpy().copy()
                 res["denom"] = gm.denom.detach().cpu().numpy().copy()
                 res["max_radii"] = gm.max_radii2D.detach().cpu().numpy().copy()
