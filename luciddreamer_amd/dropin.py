@@ -21,6 +21,9 @@ What is replaced (each one individually switchable; `uninstall(handle)` puts eve
   densify / prune / ply  densify.patch(cls): prune_points, densification_postfix, densify_and_clone / _split / _and_prune,
                          save_ply / load_ply over the library's row store.
 
+  backward               `loss.backward()` runs on the calling thread (torch.autograd.set_multithreading_enabled(False)) while
+                         installed: no hand-off to the autograd engine's device thread per iteration.
+
 Functions the caller imported BY NAME before install() ran (`from gaussian_renderer import render`, `from utils.loss import
 l1_loss, ssim` at the top of R/luciddreamer.py) are re-bound in every loaded module that holds the original object.
 """
@@ -177,16 +180,25 @@ def _raw_ok(pc, opt, override_color):
 
 
 def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=True, losses=True, adam=True, stats=True,
-            densify=True, rebind=True, lazy_filter=True):
+            densify=True, rebind=True, lazy_filter=True, backward_on_calling_thread=True):
     """gaussian_renderer, loss: the reference's modules (or None to leave alone); gaussian_model: its GaussianModel class or
     the module that defines it.  lazy_filter: the visibility filter the replaced render returns keeps the caller's masked
-    max-radii update on the device (_VisFilter above); False = a plain bool tensor.  A single namespace with attributes `gaussian_renderer`, `loss`, `gaussian_model` (what
+    max-radii update on the device (_VisFilter above); False = a plain bool tensor.  backward_on_calling_thread:
+    torch.autograd.set_multithreading_enabled(False) until uninstall() -- `loss.backward()` then runs its nodes on the thread
+    that called it instead of handing them to the autograd engine's device thread and waiting: on this path (a few dozen
+    short nodes per iteration, every one of them only ENQUEUES work) the hand-off and the two threads' turns at the
+    interpreter lock cost more than the nodes -- the unchanged loop at 1 M Gaussians / 512^2 went 2.09 -> 1.28 ms per iteration
+    on the same box (profiles/r04q_loop_segments_backward_thread.txt).  A single namespace with attributes `gaussian_renderer`, `loss`, `gaussian_model` (what
     oracle/ref_python.reference_modules yields) may be passed as the first argument.  Returns a handle for uninstall()."""
     if gaussian_renderer is not None and loss is None and gaussian_model is None and hasattr(gaussian_renderer, "gaussian_renderer"):
         ns = gaussian_renderer
         gaussian_renderer, loss, gaussian_model = ns.gaussian_renderer, getattr(ns, "loss", None), getattr(ns, "gaussian_model", None)
     cls = getattr(gaussian_model, "GaussianModel", gaussian_model)
     h = _Handle()
+    h.multithreading = None
+    if backward_on_calling_thread and hasattr(torch.autograd, "set_multithreading_enabled"):
+        h.multithreading = torch.autograd.is_multithreading_enabled()
+        torch.autograd.set_multithreading_enabled(False)
     from . import densify as dz, gaussian_renderer as gr
     from .loss import PairedLoss
     from .optim import FusedAdam
@@ -262,3 +274,6 @@ def uninstall(handle):
             except AttributeError:
                 pass
     handle.undo = []
+    if getattr(handle, "multithreading", None) is not None:
+        torch.autograd.set_multithreading_enabled(handle.multithreading)
+        handle.multithreading = None

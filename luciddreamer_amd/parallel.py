@@ -476,6 +476,16 @@ def sparse_rows_all_reduce(views: Sequence[torch.Tensor], touched: Optional[torc
             "dense_equivalent_bytes": ring_allreduce_bytes(P * K, n)}
 
 
+def _calling_thread_backward():
+    """Context: backward passes started inside run their nodes on THIS thread (torch.autograd.set_multithreading_enabled(False))
+    instead of being handed to the autograd engine's device thread -- every node of this path only enqueues kernels, and the
+    hand-off (plus the two threads taking turns at the interpreter lock) was 110-130 us of a view's 180 us of host time."""
+    import contextlib
+    if hasattr(torch.autograd, "set_multithreading_enabled"):
+        return torch.autograd.set_multithreading_enabled(False)
+    return contextlib.nullcontext()
+
+
 def _direct_backward(out: torch.Tensor, grad_output: torch.Tensor) -> bool:
     """Backward of ONE rasterizer node without the autograd engine: `out` must be the image returned by the rasterizer op,
     every differentiable input of the node a LEAF (its next function an AccumulateGrad, or none), and fused gradient
@@ -605,7 +615,8 @@ class ViewStreams:
             if backward_fn is not None:
                 if self._prev_bwd is not None:
                     s.wait_event(self._prev_bwd)
-                backward_fn(out)
+                with _calling_thread_backward():
+                    backward_fn(out)
                 ev = self._events[self._i % len(self._events)]
                 ev.record(s)
                 self._prev_bwd = ev
@@ -615,7 +626,7 @@ class ViewStreams:
                     self._deferred.append((out, grad_output))
                     if len(self._deferred) >= self.group:
                         self._flush()
-                redo = lambda o, g=grad_output: torch.autograd.backward([o], [g])
+                redo = lambda o, g=grad_output: torch.autograd.backward([o], [g])     # (end_step: a lost view, run again)
             if entry is not None:
                 self._views.append((entry, forward_fn, redo))
         except BaseException:
@@ -630,7 +641,8 @@ class ViewStreams:
         if self._deferred:
             outs, grads = zip(*self._deferred)
             self._deferred = []
-            torch.autograd.backward(list(outs), list(grads))
+            with _calling_thread_backward():
+                torch.autograd.backward(list(outs), list(grads))
 
     def end_step(self):
         from . import config

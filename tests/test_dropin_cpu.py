@@ -47,7 +47,9 @@ def test_install_replaces_rebinds_falls_through_and_uninstall_restores():
     try:
         orig = (gr.render, ls.l1_loss, ls.ssim, gm.GaussianModel.training_setup, gm.GaussianModel.add_densification_stats,
                 gm.GaussianModel.densify_and_prune)
+        assert torch.autograd.is_multithreading_enabled()
         h = luciddreamer_amd.install(gr, ls, gm)
+        assert not torch.autograd.is_multithreading_enabled()                         # backward on the calling thread while installed
         assert gr.render is not orig[0] and caller.render is gr.render               # re-bound in the module that imported it by name
         assert caller.l1_loss is ls.l1_loss and caller.ssim is ls.ssim and ls.l1_loss is not orig[1]
         assert gm.GaussianModel.densify_and_prune is not orig[5] and hasattr(gm.GaussianModel, "save_ply")
@@ -68,6 +70,7 @@ def test_install_replaces_rebinds_falls_through_and_uninstall_restores():
         m.add_densification_stats(types.SimpleNamespace(grad=None), torch.zeros(3, dtype=torch.bool))
         assert calls[-1] == "stats"
         luciddreamer_amd.uninstall(h)
+        assert torch.autograd.is_multithreading_enabled()
         now = (gr.render, ls.l1_loss, ls.ssim, gm.GaussianModel.training_setup, gm.GaussianModel.add_densification_stats,
                gm.GaussianModel.densify_and_prune)
         assert all(x is y for x, y in zip(orig, now)) and caller.render is orig[0] and caller.ssim is orig[2]

@@ -23,6 +23,8 @@ targets, depths = _targets(hidden, cams)
 order = [int(i) for i in np.random.default_rng(9).integers(0, 8, size=iters)]
 config.reset()
 config.set_async(True, on_overflow=os.environ.get("LR_POLICY", "verify"))
+if os.environ.get("LR_SINGLE_THREAD_BACKWARD"):
+    torch.autograd.set_multithreading_enabled(False)      # backward nodes on the calling thread: no hand-off to the engine's thread
 if "--hand" in sys.argv:
     # the hand-edited iteration of bench.py's `with_optional_pieces` leg, same clock
     import importlib.util
