@@ -241,6 +241,10 @@ class Workload:
 
 def timed(step, n_steps, world, dev):
     """K steps between barrier + synchronize on both sides; MAX over ranks.  Returns (seconds, host ms to issue a step)."""
+    # before the clock: what the set-up of this leg created is still in the Python collector's young generations, and the first
+    # collection inside a timed region of a few milliseconds would walk all of it (50-90 ms: profiles/r04q_loop_drift.txt)
+    import gc
+    gc.collect()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -779,6 +783,8 @@ def run_cpu_baseline(wl):
                 model = ex.TrainableCloud(b["means3D"], b["scales"], b["rotations"], b["opacities"], b["shs"])
                 model.training_setup({"xyz": 1.6e-4, "f_dc": 2.5e-3, "f_rest": 2.5e-3 / 20, "opacity": 0.05, "scaling": 5e-3,
                                       "rotation": 1e-3})
+                import gc
+                gc.collect()                                      # as ref_loop.resident(): the set-up's objects are old now
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for it in range(iters):

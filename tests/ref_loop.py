@@ -88,8 +88,15 @@ def resident(R, gm, device, cams, targets, depth_targets=None, iters=200, opt=No
     opt.iterations = iters + 1
     if gm.optimizer is None:
         gm.training_setup(opt)
-    return ([c.to(device) for c in cams], [t.to(device) for t in targets],
-            None if depth_targets is None else [t.to(device) for t in depth_targets], opt)
+    out = ([c.to(device) for c in cams], [t.to(device) for t in targets],
+           None if depth_targets is None else [t.to(device) for t in depth_targets], opt)
+    # everything the set-up created (modules, model, targets: ~10^5 Python objects) is still in the collector's young
+    # generations; the first collection inside a short timed loop would walk all of it -- 50-90 ms, i.e. +0.6-1.1 ms per
+    # iteration of an 80-iteration pass, in some passes and not in others (profiles/r04q_loop_drift.txt).  A training run pays
+    # that once; a timed pass must not: collect now, so that what survives is old
+    import gc
+    gc.collect()
+    return out
 
 
 @contextlib.contextmanager

@@ -43,6 +43,10 @@ for p in range(8):
             gm = ref_loop.model_from_cloud(R, base, dev)
             cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)
             torch.cuda.synchronize()
+            if "--freeze" in sys.argv:
+                gc.collect()
+                gc.freeze()                       # what exists now is never scanned again: a full collection stays cheap
+            g0 = [s_["collections"] for s_ in gc.get_stats()]
             pr = None
             if "--profile" in sys.argv and p in (1, 3):
                 import cProfile
@@ -62,8 +66,11 @@ for p in range(8):
                 print("\n".join(ln for ln in out.getvalue().splitlines() if ln.strip())[:2600], flush=True)
         finally:
             luciddreamer_amd.uninstall(h)
+    g1 = [s_["collections"] for s_ in gc.get_stats()]
+    if "--freeze" in sys.argv:
+        gc.unfreeze()
     st = torch.cuda.memory_stats()
     print(f"pass {p}: {dt:.3f} ms / iteration; reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB, "
           f"device mallocs {st.get('num_device_alloc', -1)}, frees {st.get('num_device_free', -1)}, gc objects {len(gc.get_objects())}, "
-          f"modules {len(sys.modules)}, sclk {sclk()}", flush=True)
+          f"collections in the pass (gen 0/1/2) {[b - a for a, b in zip(g0, g1)]}, sclk {sclk()}", flush=True)
     del gm
