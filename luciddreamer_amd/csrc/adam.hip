@@ -13,6 +13,7 @@
 // HBM-bound, 28 B per element.
 #include "common.h"
 #include <cmath>
+#include <cstdint>
 
 namespace lr {
 
@@ -40,18 +41,34 @@ k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps
     float* __restrict__ v = T.v[t];
     const unsigned long long n = T.n[t];
     const float step_size = T.step_size[t];
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
-        const float gi = g[i];
-        float mi = m[i], vi = v[i];
-        // the same roundings as torch's kernels (which hipcc compiles with FMA contraction): lerp = fma(w, b - a, a),
-        // addcmul = fma(value * t1, t2, self), addcdiv = fma(value, t1 / t2, self); mul_, sqrt, div, add are separate
+    // the same roundings as torch's kernels (which hipcc compiles with FMA contraction): lerp = fma(w, b - a, a),
+    // addcmul = fma(value * t1, t2, self), addcdiv = fma(value, t1 / t2, self); mul_, sqrt, div, add are separate
+    auto one = [&](float gi, float& mi, float& vi, float& pi) {
         mi = __builtin_fmaf(w1, gi - mi, mi);
         vi = vi * beta2;
         vi = __builtin_fmaf(w2 * gi, gi, vi);
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] = __builtin_fmaf(-step_size, mi / denom, p[i]);
-        m[i] = mi;
-        v[i] = vi;
+        pi = __builtin_fmaf(-step_size, mi / denom, pi);
+    };
+    // 16 bytes per lane and access (the four arrays are whole allocations: 16-byte aligned); round 3 moved one float per
+    // lane and reached 4.6-5.3 TB/s of the 6.29 TB/s this part streams
+    const bool wide = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                        reinterpret_cast<uintptr_t>(v)) & 15u) == 0;
+    const unsigned long long n4 = wide ? n / 4 : 0;
+    float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
+    float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+    float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) {
+        const float4 gi = g4[i];
+        float4 mi = m4[i], vi = v4[i], pi = p4[i];
+        one(gi.x, mi.x, vi.x, pi.x); one(gi.y, mi.y, vi.y, pi.y); one(gi.z, mi.z, vi.z, pi.z); one(gi.w, mi.w, vi.w, pi.w);
+        p4[i] = pi; m4[i] = mi; v4[i] = vi;
+    }
+    for (unsigned long long i = 4 * n4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        float mi = m[i], vi = v[i], pi = p[i];
+        one(g[i], mi, vi, pi);
+        p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 
@@ -77,7 +94,8 @@ int launch_adam(int n_tensors, float* const* params, const float* const* grads, 
         if (on && numel[t] > max_n) max_n = numel[t];
     }
     if (max_n == 0) return 0;
-    unsigned long long blocks = (max_n + 255) / 256;
+    unsigned long long blocks = (max_n / 4 + 255) / 256;            // a thread moves four elements per turn
+    if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks, n_tensors), dim3(256), 0, s, T, (float)(1.0 - beta1), (float)beta2,
                        (float)(1.0 - beta2), (float)std::sqrt(bc2), (float)eps);

@@ -43,6 +43,31 @@ def test_matches_torch_adam(hip_device):
         assert close(sb["exp_avg"], sa["exp_avg"]) and close(sb["exp_avg_sq"], sa["exp_avg_sq"]), k
 
 
+def test_odd_sizes_and_unaligned_tensors_take_the_same_steps(hip_device):
+    """The kernel moves 16 bytes per lane where all four arrays are 16-byte aligned and finishes the tail (and whole tensors that
+    are not aligned: a parameter that is a view at an odd offset) one float at a time; every element must take the step torch
+    takes, whichever path it is on."""
+    from luciddreamer_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(3)
+    sizes = [1, 3, 5, 1021, 4096 + 7]
+    base = [torch.randn(n + 1, generator=g).to(hip_device) for n in sizes]
+    a = [nn.Parameter(t[:-1].clone()) for t in base]                       # aligned, numel % 4 != 0
+    b = [nn.Parameter(t[:-1].clone()) for t in base]
+    ua, ub = nn.Parameter(base[-1].clone()[1:]), nn.Parameter(base[-1].clone()[1:])     # 4 bytes off a 16-byte boundary
+    assert ub.data_ptr() % 16 == 4 and ub.is_contiguous()
+    ref = torch.optim.Adam(a + [ua], lr=1e-2, eps=1e-15)
+    fus = FusedAdam(b + [ub], lr=1e-2, eps=1e-15)
+    for it in range(7):
+        for x, y in zip(a + [ua], b + [ub]):
+            gr = torch.randn(x.shape, generator=g).to(hip_device)
+            x.grad, y.grad = gr.clone(), gr.clone()
+        ref.step()
+        fus.step()
+    for x, y in zip(a + [ua], b + [ub]):
+        assert (x - y).abs().max().item() <= 2e-6 * max(x.abs().max().item(), 1e-12), x.shape
+        assert (ref.state[x]["exp_avg_sq"] - fus.state[y]["exp_avg_sq"]).abs().max().item() <= 2e-6 * ref.state[x]["exp_avg_sq"].abs().max().item()
+
+
 def test_params_without_grad_are_skipped_and_cpu_is_rejected(hip_device):
     from luciddreamer_amd.optim import FusedAdam
     p = _params(100, hip_device, 3)
