@@ -165,10 +165,11 @@ class Workload:
         if api in ("views", "views-loss"):
             named = {"means3D": leaf["means3D"], "scales": leaf["scales"], "rotations": leaf["rotations"],
                      "opacity": leaf["opacities"], "sh": leaf["shs"]}
-            # two view groups (the first bucket's all-reduce runs under the second group) only when a rank has enough
-            # views to hide a collective behind: it doubles the bytes on the links, which a step of a few views per
-            # rank -- communication bound -- cannot afford
-            self.chunks = chunks = (2 if len(self.cams) >= 8 else 1) if self.world > 1 else 1
+            # ONE all-reduce after the rank's last view.  (Rounds 2-4 split a rank's views into two groups and ran the first
+            # group's all-reduce under the second group: every group reduces a FULL bucket -- each view touches rows of every
+            # tensor -- so the step is c1 + max(ar, c2) + ar against c + ar unsplit: never shorter, and twice the bytes on the
+            # links when the step is communication bound.  parallel.ChunkedViewStep still takes chunks = 2 for A/B runs.)
+            self.chunks = chunks = 1
             if api == "views" and getattr(self.args, "exchange", "allreduce") == "sharded-adam":
                 # the step as a TRAINING step (not the metric: it adds the optimizer): no all-reduce -- reduce-scatter of the
                 # bucket, Adam on this rank's shard, all-gather of the parameters (parallel.ShardedAdam)

@@ -294,19 +294,20 @@ class ShardedAdam:
             dist.all_gather_into_tensor(flat_p, p_shard)      # in place: rank r's input IS slice r of the output
 
 
-REDUCE_CHUNKS = 2
+REDUCE_CHUNKS = 1
 
 
 class ChunkedViewStep:
-    """The multi-view step of one rank with the gradient all-reduce overlapped with rendering.
+    """The multi-view step of one rank with its gradient exchange: zero the bucket, render every view forward + backward into it
+    (ViewBatch: lr_views_accumulate), all-reduce the bucket.
 
-    One blocking all-reduce after the last view leaves the xGMI links idle for the whole step and the GPU idle for the
-    whole collective (236 MB at 1 M Gaussians: 1.4-2.7 ms against a 7 ms step).  Gradients cannot be reduced per
-    parameter tensor as they become final -- every tensor is written by every view's last kernel -- so the step is split
-    along the VIEWS instead: the rank's views form REDUCE_CHUNKS consecutive groups, each accumulating into its own flat
-    bucket; as soon as a group is enqueued its bucket is all-reduced asynchronously (RCCL works on its own stream, after
-    the group's kernels) while the next group renders; the buckets are summed at the end (one 2 x 236 B/Gaussian pass).
-    With one rank (or chunks=1) this is exactly ViewBatch + FlatGrads.all_reduce.
+    `chunks` > 1 splits the rank's views into consecutive groups with a bucket each and starts a group's all-reduce as soon as
+    the group is enqueued (RCCL works on its own stream) while the next group renders; the buckets are summed at the end.
+    It is NOT the default and cannot pay on this path: gradients cannot be reduced per parameter tensor as they become final --
+    every tensor is written by every view's last kernel -- so every group reduces a FULL bucket, and the step is
+    c1 + max(ar, c2) + ar against c + ar for one exchange after the last view (ar = one all-reduce, c = c1 + c2 the rendering):
+    never shorter, and twice the bytes on the xGMI links in the regime where the step is communication bound (a few views per
+    rank).  Kept for A/B runs on a node; with chunks = 1 (default) this is exactly ViewBatch + FlatGrads.all_reduce.
 
     named_params: {"means3D", "scales", "rotations", "opacity", "sh"} -> parameter tensors (their .grad become views of
     the primary bucket, `self.grads`)."""
