@@ -467,6 +467,30 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     }
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one process per
+    GPU of this node, backend nccl (= RCCL).  Fails loudly -- no N = 1 fallback -- when the node shows fewer than N devices
+    (LR_DIST_BACKEND=gloo lets the ranks share devices: the 1-GPU debugging configuration of tests/test_gpu_distributed.py).
+    Returns the exit code of the launcher."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    backend = os.environ.get("LR_DIST_BACKEND") or "nccl"
+    if have < n and backend == "nccl":
+        print(f"[bench] --gpus {n} needs {n} HIP devices on this node, {have} visible: RCCL does not run two ranks on one "
+              f"device.  Not falling back to fewer ranks.  (LR_DIST_BACKEND=gloo shares devices between ranks for debugging.)",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as sock:                       # a free rendezvous port on the loopback interface
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] starting {n} ranks: {' '.join(cmd[1:8])} ... (backend {backend})", file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,11 +530,24 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))            # plain `python bench.py --gpus N`: start the N ranks ourselves
     rank, world, dev = parallel.init_distributed()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        # never a silent N = 1 line under --gpus N: the launcher's world size and the flag must agree
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` alone: it starts the ranks itself)")
     backend = torch.distributed.get_backend() if world > 1 else None
     backend_world = torch.distributed.get_world_size() if world > 1 else 1
+    collective_check = None
+    if world > 1:
+        # proof that the collective ran over `world` ranks on the backend named in the line: an all-reduce of ones
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        collective_check = {"all_reduce_of_ones": float(ones.item()), "ranks": backend_world, "backend": backend,
+                            "devices_visible": torch.cuda.device_count()}
+        if int(round(collective_check["all_reduce_of_ones"])) != args.gpus:
+            raise SystemExit(f"[bench] all-reduce of ones over the ranks gave {collective_check['all_reduce_of_ones']}, not {args.gpus}")
 
     res = tuple(int(v) for v in args.resolution.lower().split("x")) if args.resolution else None
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
@@ -614,7 +651,8 @@ def main():
                                                  int(2 * (world - 1) * bucket_bytes * chunks // world)) if world > 1 else 0,
                     "allreduce_payload_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
                     "exchange_detail": exchange_detail,
-                    "dist_backend": backend, "dist_world_size": backend_world, "streams_per_rank": args.streams,
+                    "dist_backend": backend, "dist_world_size": backend_world, "collective_check": collective_check,
+                    "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
         line = {

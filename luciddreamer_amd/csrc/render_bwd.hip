@@ -559,6 +559,372 @@ k_render_bwd_tile(LR_BWD_PARAMS) { render_bwd_tile<44>(LR_BWD_PASS); }
 // the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_render_bwd_tile7(LR_BWD_PARAMS) { render_bwd_tile<64>(LR_BWD_PASS); }
+
+// ---- the MFMA-transposed reduction (round 5) ---------------------------------------------------------------------------
+// What the shapes above pay per candidate and wave for the nine sums -- six lane swaps, six adds and seven DPP adds (88 issue
+// cycles at the measured costs, a third of the kernel) after five multiplies that form the moments -- is here two
+// v_mfma_f32_16x16x4_f32 pairs and eight FMAs, and the matrix pipe is otherwise idle.  Round 2 used the instruction as a
+// 64 -> 16 lane adder, one per term (nine per candidate: the matrix pipe became the limit, profiles/r02m).  Here it is used
+// as a TRANSPOSER.  With lane l = i + 16 k (i = l & 15, k = l >> 4) supplying A[i][k] = u[l] (the lane's datum) and
+// B[k][j] = b[l] (a lane CONSTANT), the result D[i][j] = sum_k u[i + 16 k] b_j(k) lands in lane (j, q = l >> 4), register r,
+// for i = 4 q + r: the datum's lane index i has moved into (row of lanes, register).  There a lane multiplies its four
+// registers by four more lane constants W_j(4 q + r) and adds them up (one v_mul + three v_fma): P[q][j].  A second MFMA with
+// A = 1 sums P over the four rows q:   total_j = sum_{i,k} u[i + 16 k] W_j(i) b_j(k),  for SIXTEEN different j at once --
+// every sum over the wave's 64 lanes of the datum times a weight that is separable in (i, k), or a sum of such.
+//   * the six moments of D = opacity G dL/dalpha are sums with weights 1, X, Y, X^2, XY, Y^2 in pixel coordinates relative
+//     to the centre of the wave's box (exact small half-integers; the flush shifts them to the splat's centre per staged
+//     element, once, in float): with x = i & 7, h = i >> 3, y = 2 k + h that is 14 separable columns (mf_w / mf_b below;
+//     9 when the lane owns one pixel).  A lane with several pixels (slots) chains their MFMAs through the accumulator
+//     operand: the slot's offset inside the box enters only through b.
+//   * the three colour sums weigh dchan = alpha T by the pixel's own dL/dpixel -- not separable; b = one-hot in k makes the
+//     first MFMA a pure transpose (column j = 4 t + k0 receives u[i + 16 k0]), the weights W are the pixel gradients
+//     transposed the same way once per kernel (by the same instruction), twelve columns.
+// The pixel step loses the five moment / colour multiplies; the candidate loop ends with one 26-lane ds_write into the wave's
+// own column block of the staged element; the flush reads back the blocks of the waves that met the element (the cull
+// predicate is recomputed there: nothing is zeroed).  Sums are fixed-order FMA chains inside the instruction: bit-repeatable.
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int MF_NCM = 14;                  // moment columns of a lane with several pixels; 9 with one (no slot offsets)
+template <int NSLOT> struct MfCols {
+    static constexpr int n = NSLOT == 1 ? 9 : MF_NCM;
+    // physical column (lane of the column totals, word of the wave's block) -> logical column c0..c13 below
+    __device__ static constexpr int logical(int phys)
+    {
+        if (NSLOT != 1) return phys < MF_NCM ? phys : -1;
+        constexpr int map[9] = { 0, 1, 3, 6, 7, 8, 9, 12, 13 };
+        return phys < 9 ? map[phys] : -1;
+    }
+    __device__ static constexpr int phys(int logical_col)
+    {
+        if (NSLOT != 1) return logical_col;
+        constexpr int inv[14] = { 0, 1, -1, 2, -1, -1, 3, 4, 5, 6, -1, -1, 7, 8 };
+        return inv[logical_col];
+    }
+};
+// column j of the moment reduction: weight W_j(i) b_j(k); X = xc + sx, Y = Yk + yh with xc = (i & 7) - 3.5, yh = (i >> 3) - 0.5,
+// Yk = 2 k - 3 + sy, (sx, sy) = offset of the slot's 8x8 quadrant centre from the box centre
+//   M0 = c0   MX = c1 + c2   MXX = c3 + c4 + c5   MY = c6 + c7   MXY = c8 + c9 + c10 + c11   MYY = c12 + c13 + M0 / 4
+__device__ __forceinline__ float mf_w(int j, int i)
+{
+    const float xc = (float)(i & 7) - 3.5f, yh = (float)(i >> 3) - 0.5f;
+    switch (j) {
+        case 0: case 2: case 5: case 6: case 10: case 12: return 1.f;
+        case 1: case 4: case 8: return xc;
+        case 3: return xc * xc;
+        case 7: case 11: case 13: return yh;
+        case 9: return xc * yh;
+        default: return 0.f;
+    }
+}
+__device__ __forceinline__ float mf_b(int j, int k, float sx, float sy)
+{
+    const float Yk = (float)(2 * k - 3) + sy;
+    switch (j) {
+        case 0: case 1: case 3: case 7: case 9: return 1.f;
+        case 2: case 11: return sx;
+        case 4: return 2.f * sx;
+        case 5: return sx * sx;
+        case 6: case 8: return Yk;
+        case 10: return sx * Yk;
+        case 12: return Yk * Yk;
+        case 13: return 2.f * Yk;
+        default: return 0.f;
+    }
+}
+
+// the pixel step of the shapes above without the lane sums: returns dop = opacity G dL/dalpha and dchan = alpha T
+template <bool CHECK_LAST, bool STRICT>
+__device__ __forceinline__ void bwd_pixel_mf(BwdPix& p, const float qA, const float qB, const float qC, const float r0, const float r1,
+                                             const float gx, const float op, const float cr, const float cg, const float cb,
+                                             const uint32_t pos, float& dop, float& dchan)
+{
+    const float dx = gx - p.pxf;
+    float power;
+    const float t = op * gauss_weight<STRICT>(qA, qB, qC, r0, r1, dx, power);
+    const bool v = (!CHECK_LAST || pos < p.last) && power <= 0.0f && t >= 1.0f / 255.0f;
+    const float tm = v ? t : 0.f;
+    const float alpha = fminf(0.99f, tm);
+    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+    p.T = p.T * rinv;
+    dchan = alpha * p.T;
+    const float d = __builtin_fmaf(cb, p.dLb, __builtin_fmaf(cg, p.dLg, __builtin_fmaf(cr, p.dLr, -p.A)));
+    dop = tm * (d * p.T);
+    p.A = __builtin_fmaf(alpha, d, p.A);
+}
+
+// NSLOT pixels per lane: 1 = four waves per tile, a wave owns an 8x8 quadrant (small images); 2 = two waves, a wave owns a
+// 16x8 half tile; 4 = one wave per tile.  Slot s of a lane is the pixel (l & 7, l >> 3) of quadrant s of the wave's box.
+// CMF: colour sums through the matrix pipe as well (false: lane sums + swaps / DPP adds, three terms).
+template <int NSLOT, bool CMF, bool STRICT, int BATCH>
+__device__ __forceinline__ void render_bwd_mf(LR_BWD_PARAMS)
+{
+    constexpr int NWAVES = 4 / NSLOT;
+    constexpr int NCC = CMF ? 12 : 3;                  // colour columns
+    constexpr int NCM = MfCols<NSLOT>::n;              // moment columns
+    constexpr int NACC = NCM + NCC;                    // floats a wave leaves per staged element it met
+    constexpr int STRIDE = (NWAVES * NACC) | 1;        // odd: the flush (lane = staged element) reads without bank conflicts
+    __shared__ float4 s_q0[BATCH];      // as k_render_bwd
+    __shared__ float4 s_q1[BATCH];
+    __shared__ float4 s_q2[BATCH];
+    __shared__ uint32_t s_id[BATCH];
+    __shared__ uint32_t s_hit[BATCH];
+    __shared__ float s_acc[BATCH * STRIDE];
+    __shared__ uint32_t s_lastq[4];     // deepest last contributor per quadrant of the tile (q = x half + 2 * y half)
+
+    const int tile = blend_tile(tile_map, num_tiles);
+    if (tile < 0) return;
+    if (hdr->overflow != 0u) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
+    // the wave's box and its first quadrant
+    const int q0 = NSLOT == 1 ? w : NSLOT == 2 ? 2 * w : 0;
+    const int bx = tx * TILE_X + (q0 & 1) * 8, by = ty * TILE_Y + (q0 >> 1) * 8;
+    const size_t N = (size_t)W * H;
+
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+    if (total == 0) return;
+    const BinLayout BL = bin_layout((long long)hdr->bin_bound);
+    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
+    float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
+    const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
+
+    BwdPix P[NSLOT];
+    uint32_t lastq[NSLOT];
+    bool stopped = false;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) {
+        const int px = bx + (s & 1) * 8 + (l & 7), py = by + (s >> 1) * 8 + (l >> 3);
+        const bool ins = px < W && py < H;
+        const size_t pix = (size_t)py * W + px;
+        P[s].pxf = (float)px;
+        P[s].T = ins ? final_Ts[pix] : 0.f;
+        P[s].last = ins ? n_contrib[pix] : 0u;
+        P[s].dLr = ins ? dL_dpix[pix] : 0.f;
+        P[s].dLg = ins ? dL_dpix[N + pix] : 0.f;
+        P[s].dLb = ins ? dL_dpix[2 * N + pix] : 0.f;
+        P[s].A = bg0 * P[s].dLr + bg1 * P[s].dLg + bg2 * P[s].dLb;
+        lastq[s] = wave_max_u32(P[s].last);
+        stopped = stopped || (ins && P[s].last < (uint32_t)total);
+        if (l == 0) s_lastq[q0 + s] = lastq[s];
+    }
+    const float pyf0 = (float)(by + (l >> 3)), pyf1 = pyf0 + 8.0f;          // the lane's row in the upper / lower quadrants
+    const bool any_stopped = force_check != 0 || __ballot(stopped) != 0ull;
+    const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
+    const float ddely_dy = (float)(0.5 * H);
+
+    // lane constants of the reduction.  As the B operand of the first MFMA this lane is (k = l >> 4, column j = l & 15); as a
+    // holder of its result it is (column j = l & 15, row q = l >> 4) with registers r <-> i = 4 q + r.
+    const int cj = l & 15, cq = l >> 4;
+    float b1m[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++)
+        b1m[s] = mf_b(MfCols<NSLOT>::logical(cj), cq, NSLOT == 1 ? 0.f : ((s & 1) ? 4.f : -4.f), NSLOT == 4 ? ((s >> 1) ? 4.f : -4.f) : 0.f);
+    float Wm[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) Wm[r] = mf_w(MfCols<NSLOT>::logical(cj), 4 * cq + r);
+    const float b1c = (cj < 12 && cq == (cj & 3)) ? 1.f : 0.f;
+    float Wc[CMF ? NSLOT : 1][4];
+    if (CMF) {
+        // transposed pixel gradients: Wc[s][r] of lane (j, q) = dL_{t = j >> 2} of the pixel of lane (4 q + r) + 16 (j & 3)
+        const float b1t = (cq == (cj & 3)) ? 1.f : 0.f;
+        const v4f z = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+        for (int s = 0; s < NSLOT; s++) {
+            const v4f tr = mfma4(P[s].dLr, b1t, z), tg = mfma4(P[s].dLg, b1t, z), tb = mfma4(P[s].dLb, b1t, z);
+#pragma unroll
+            for (int r = 0; r < 4; r++) Wc[s][r] = cj < 4 ? tr[r] : cj < 8 ? tg[r] : cj < 12 ? tb[r] : 0.f;
+        }
+    }
+    // the store that ends a candidate: moments from lanes 0-13, colours from lanes 16-27 (CMF) / the row leaders 16, 32, 48
+    const bool writer = CMF ? (cq == 0 ? cj < NCM : (cq == 1 && cj < 12)) : (cq == 0 ? cj < NCM : cj == 0);
+    const int woff = w * NACC + (CMF ? (cq == 0 ? cj : NCM + cj) : (cq == 0 ? cj : NCM + cq - 1));
+    const bool row0 = cq == 0;
+
+    lds_barrier();
+    uint32_t tile_last = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) tile_last = max(tile_last, s_lastq[i]);
+    uint32_t wave_last = 0;
+#pragma unroll
+    for (int s = 0; s < NSLOT; s++) wave_last = max(wave_last, lastq[s]);
+
+    for (int base = 0; base < total; base += BATCH) {
+        const int cnt = min(BATCH, total - base);
+        const int pos_hi = total - 1 - base;             // position of staged element 0 (back to front)
+        const int pos_lo = pos_hi - (cnt - 1);
+        if ((uint32_t)pos_lo >= tile_last) {             // whole batch behind every last contributor: slots read as zero
+            if (tid < cnt) {
+                float4* slot = inst_grad + 3 * (size_t)point_list[range.x + (pos_hi - tid)];
+                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f); slot[1] = slot[0]; slot[2] = slot[0];
+            }
+            continue;
+        }
+        lds_barrier();
+        if (tid < cnt) {
+            const uint32_t e = point_list[range.x + (pos_hi - tid)];
+            s_hit[tid] = quad_hits[range.x + (pos_hi - tid)];
+            const uint32_t id = inst_gid[e];
+            const float4* g = reinterpret_cast<const float4*>(rec + id);
+            const float4 a = g[0], b = g[1], c = g[2];
+            s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            *reinterpret_cast<float2*>(&s_q1[tid]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
+            s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
+            s_id[tid] = e;
+        }
+        lds_barrier();
+
+        for (int sb = 0; sb < cnt; sb += 64) {
+            // CULL (as k_render_bwd): the forward's quadrant tests, each quadrant with its own deepest last contributor
+            uint64_t m[NSLOT];
+            {
+                const int j = sb + l;
+                const uint32_t pos = (uint32_t)(pos_hi - j);
+                const uint32_t h = (j < cnt && pos < wave_last) ? (s_hit[j] >> (8 * q0)) : 0u;
+#pragma unroll
+                for (int s = 0; s < NSLOT; s++) m[s] = __ballot(pos < lastq[s] && ((h >> (8 * s)) & 0xffu) != 0u);
+            }
+            uint64_t mask = m[0];
+#pragma unroll
+            for (int s = 1; s < NSLOT; s++) mask |= m[s];
+            auto walk = [&](auto chk) {
+            constexpr bool CHECK = decltype(chk)::value;
+            while (mask) {
+                const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
+                mask &= mask - 1;
+                const int j = sb + k;
+                const uint32_t pos = (uint32_t)(pos_hi - j);
+                const float4 a = s_q0[j];
+                const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);   // Cp, opacity
+                const float4 c = s_q2[j];
+                v4f accm = { 0.f, 0.f, 0.f, 0.f };
+                float Pc = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
+#pragma unroll
+                for (int half = 0; half < (NSLOT == 4 ? 2 : 1); half++) {        // slots of one row of quadrants share dy
+                    const int s0 = 2 * half;
+                    if constexpr (NSLOT == 4) {
+                        if (!(((m[s0] | m[s0 + 1]) >> k) & 1ull)) continue;
+                    }
+                    const float dys = a.y - (half ? pyf1 : pyf0);
+                    float r0, r1;
+                    gauss_row<STRICT>(a.w, b.x, dys, r0, r1);
+#pragma unroll
+                    for (int u = 0; u < (NSLOT >= 2 ? 2 : 1); u++) {
+                        const int s = s0 + u;
+                        bool hit = true;
+                        if constexpr (NSLOT > 1) hit = (m[s] >> k) & 1ull;
+                        if (hit) {
+                            float dop, dchan;
+                            bwd_pixel_mf<CHECK, STRICT>(P[s], a.z, a.w, b.x, r0, r1, a.x, b.y, c.x, c.y, c.z, pos, dop, dchan);
+                            accm = mfma4(dop, b1m[s], accm);
+                            if (CMF) {
+                                const v4f z = { 0.f, 0.f, 0.f, 0.f };
+                                const v4f t = mfma4(dchan, b1c, z);
+                                Pc = __builtin_fmaf(Wc[s][3], t[3], __builtin_fmaf(Wc[s][2], t[2],
+                                     __builtin_fmaf(Wc[s][1], t[1], __builtin_fmaf(Wc[s][0], t[0], Pc))));
+                            } else {
+                                sR = __builtin_fmaf(dchan, P[s].dLr, sR);
+                                sG = __builtin_fmaf(dchan, P[s].dLg, sG);
+                                sB = __builtin_fmaf(dchan, P[s].dLb, sB);
+                            }
+                        }
+                    }
+                }
+                const float Pm = __builtin_fmaf(Wm[3], accm[3], __builtin_fmaf(Wm[2], accm[2], __builtin_fmaf(Wm[1], accm[1], Wm[0] * accm[0])));
+                const v4f z = { 0.f, 0.f, 0.f, 0.f };
+                float val = mfma4(1.0f, Pm, z)[0];                 // every row of lanes: column totals, lane j <-> column j
+                if (CMF) {
+                    const float vc = mfma4(1.0f, Pc, z)[0];
+                    val = row0 ? val : vc;
+                } else {
+                    // three lane sums over the wave: two swap levels leave R | B | G | B in the rows, a row sum finishes
+                    // three lane sums over the wave: two swap levels leave B | R | G | B in the four rows of lanes (as
+                    // reduce8), a row sum finishes; rows 1-3 hand R, G, B to their first lane
+                    float sB2 = sB;
+                    asm volatile("s_nop 1\n\t"
+                                 "v_permlane32_swap_b32 %0, %1\n\t"
+                                 "v_permlane32_swap_b32 %2, %3\n\t"
+                                 "v_add_f32 %0, %0, %1\n\t"
+                                 "v_add_f32 %2, %2, %3\n\t"
+                                 "s_nop 0\n\t"
+                                 "v_permlane16_swap_b32 %0, %2\n\t"
+                                 "v_add_f32 %0, %0, %2\n\t"
+                                 "s_nop 1"
+                                 : "+v"(sB), "+v"(sG), "+v"(sR), "+v"(sB2));
+                    const float rc = row_sum(sB);
+                    val = row0 ? val : rc;
+                }
+                int jo = j * STRIDE;
+                asm volatile("" : "+s"(jo));
+                if (writer) s_acc[jo + woff] = val;
+            }
+            };
+            if constexpr (NSLOT == 4) walk(BoolTag<true>{});      // one copy of the loop (registers), as the TILE shape
+            else { if (any_stopped) walk(BoolTag<true>{}); else walk(BoolTag<false>{}); }
+        }
+        lds_barrier();
+        if (tid < cnt) {
+            const uint32_t pos = (uint32_t)(pos_hi - tid);
+            const uint32_t hits = s_hit[tid];
+            const float4 q0v = s_q0[tid]; const float2 q1v = *reinterpret_cast<const float2*>(&s_q1[tid]);
+            float a9[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) a9[k] = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < NWAVES; ww++) {
+                // did wave ww meet this element?  (the cull predicate of the candidate loop, restated per quadrant)
+                const int wq0 = NSLOT == 1 ? ww : NSLOT == 2 ? 2 * ww : 0;
+                bool met = false;
+#pragma unroll
+                for (int s = 0; s < NSLOT; s++) met = met || (pos < s_lastq[wq0 + s] && ((hits >> (8 * (wq0 + s))) & 0xffu) != 0u);
+                if (!met) continue;
+                const float* col = &s_acc[tid * STRIDE + ww * NACC];
+                using MC = MfCols<NSLOT>;
+                const float M0 = col[0];
+                float MX = col[MC::phys(1)], MXX = col[MC::phys(3)], MY = col[MC::phys(6)] + col[MC::phys(7)],
+                      MXY = col[MC::phys(8)] + col[MC::phys(9)], MYY = col[MC::phys(12)] + col[MC::phys(13)];
+                if constexpr (NSLOT >= 2) { MX += col[2]; MXX += col[4] + col[5]; MXY += col[10] + col[11]; }
+                MYY = __builtin_fmaf(0.25f, M0, MYY);
+                // box centre of wave ww; the moments move from there to the splat's centre (d = mean - pixel)
+                const float cx = (float)(tx * TILE_X + (wq0 & 1) * 8) + (NSLOT == 1 ? 3.5f : 7.5f);
+                const float cy = (float)(ty * TILE_Y + (wq0 >> 1) * 8) + (NSLOT == 4 ? 7.5f : 3.5f);
+                const float gxq = q0v.x - cx, gyq = q0v.y - cy;
+                const float Sx = gxq * M0 - MX, Sy = gyq * M0 - MY;
+                a9[0] += Sx;
+                a9[1] += Sy;
+                a9[2] += gxq * Sx - (gxq * MX - MXX);
+                a9[3] += gxq * Sy - (gyq * MX - MXY);
+                a9[4] += gyq * Sy - (gyq * MY - MYY);
+                a9[5] += M0;
+                if (CMF) {
+                    a9[6] += (col[NCM + 0] + col[NCM + 1]) + (col[NCM + 2] + col[NCM + 3]);
+                    a9[7] += (col[NCM + 4] + col[NCM + 5]) + (col[NCM + 6] + col[NCM + 7]);
+                    a9[8] += (col[NCM + 8] + col[NCM + 9]) + (col[NCM + 10] + col[NCM + 11]);
+                } else {
+                    a9[6] += col[NCM + 0];
+                    a9[7] += col[NCM + 1];
+                    a9[8] += col[NCM + 2];
+                }
+            }
+            const float ca = STRICT ? q0v.z : (-2.0f * LN2) * q0v.z, cb = STRICT ? q0v.w : -LN2 * q0v.w,
+                        cc = STRICT ? q1v.x : (-2.0f * LN2) * q1v.x, o = q1v.y;
+            const float sx = a9[0], sy = a9[1], hh = -0.5f;
+            const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;
+            float4* slot = inst_grad + 3 * (size_t)s_id[tid];
+            slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, hh * a9[2], hh * a9[3]);
+            slot[1] = make_float4(hh * a9[4], dopac, a9[6], a9[7]);
+            slot[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+
+// (registers: the compiler's own budget; LDS per workgroup 64 x (3 x 16 + 8) + 64 x STRIDE x 4 bytes)
+template <int NSLOT, bool CMF, bool STRICT>
+__global__ void __launch_bounds__(NSLOT == 1 ? 256 : NSLOT == 2 ? 128 : 64)
+k_render_bwd_mf(LR_BWD_PARAMS) { render_bwd_mf<NSLOT, CMF, STRICT, 64>(LR_BWD_PASS); }
 #undef LR_BWD_PARAMS
 #undef LR_BWD_PASS
 
@@ -622,6 +988,18 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
     int shape = blend_shape(num_tiles);
     const bool strict = tune_get(TUNE_STRICT) > 0;
+    // lr_tune_set("bwd_red", 5 / 6): the MFMA-transposed reduction, colour sums through the matrix pipe too / by lane swaps
+    if (red == 5 || red == 6) {
+        const int threads = shape == BLEND_QUAD ? 256 : shape == BLEND_TILE ? 64 : 128;
+#define LR_MF(NS, CMF)                                                                                                       \
+        do { if (strict) hipLaunchKernelGGL((k_render_bwd_mf<NS, CMF, true>), dim3(grid), dim3(threads), 0, s, LR_BWD_ARGS);    \
+             else hipLaunchKernelGGL((k_render_bwd_mf<NS, CMF, false>), dim3(grid), dim3(threads), 0, s, LR_BWD_ARGS); } while (0)
+        if (shape == BLEND_QUAD) { if (red == 5) LR_MF(1, true); else LR_MF(1, false); }
+        else if (shape == BLEND_TILE) { if (red == 5) LR_MF(4, true); else LR_MF(4, false); }
+        else { if (red == 5) LR_MF(2, true); else LR_MF(2, false); }
+#undef LR_MF
+        return;
+    }
     if (strict && shape == BLEND_TILE) shape = BLEND_HALF;
     if (strict) {
         if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);

@@ -499,6 +499,11 @@ def _direct_backward(out: torch.Tensor, grad_output: torch.Tensor) -> bool:
     fn = out.grad_fn
     if fn is None or not config.fused_grad_accumulation() or "Rasterize" not in type(fn).__name__ + fn.name():
         return False
+    # only the COMPILED node (csrc/torch_ext.cpp RasterizeFn, a torch::autograd::CppNode) can be called like a function;
+    # the nodes of Python autograd.Functions (the raw-parameter path render_raw, the debug-mode operator) are not callable
+    # objects on torch 2.10 ('...Backward' object is not callable): those views go through the engine
+    if "RasterizeFn" not in fn.name() or not callable(fn):
+        return False
     leaves = []
     for nxt, _ in fn.next_functions:
         if nxt is None:
@@ -507,8 +512,7 @@ def _direct_backward(out: torch.Tensor, grad_output: torch.Tensor) -> bool:
             leaves.append(nxt.variable)
         else:
             return False
-    n_out = 4 if "RasterizeFn" in fn.name() else 3               # compiled node: (color, radii, depth, geom); Python nodes: 3
-    grads = fn(grad_output, *([None] * (n_out - 1)))
+    grads = fn(grad_output, None, None, None)                    # the compiled node's outputs: (color, radii, depth, geom)
     if not isinstance(grads, (tuple, list)):
         grads = (grads,)
     with torch.no_grad():

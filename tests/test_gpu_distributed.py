@@ -117,3 +117,31 @@ def test_bench_reports_bytes_on_wire_for_both_exchanges(hip_device):
     assert sparse["exchange"] == "sparse-rows" and d["rows_sent_per_step"] > 0
     assert sparse["allreduce_bytes_per_step"] == d["bytes_all_to_all"] + d["bytes_all_gather"]
     assert d["bytes_all_to_all"] < d["dense_ring_allreduce_bytes"] // 2          # the reduce half shrank
+
+
+def test_bench_gpus_n_starts_its_own_ranks_or_refuses(hip_device):
+    """`python bench.py --gpus 2` with no launcher around it (the way the driver runs it): with RCCL it must refuse loudly
+    on a box that shows fewer than 2 devices -- never an N = 1 line under `--gpus 2` -- and with LR_DIST_BACKEND=gloo (ranks
+    sharing the device) it starts the two ranks itself and the line proves the collective ran over both."""
+    import subprocess
+    import sys
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--gaussians", "100000",
+            "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LR_DIST_BACKEND")}
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode != 0 and "needs 2 HIP devices" in r.stderr, (r.returncode, r.stderr[-2000:])
+        assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]              # no bench line at all
+    r = subprocess.run(args, env=dict(env, LR_DIST_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["dist_world_size"] == 2 and line["config"]["dist_backend"] == "gloo"
+    chk = line["config"]["collective_check"]
+    assert chk["all_reduce_of_ones"] == 2.0 and chk["ranks"] == 2
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus(hip_device):
+    """A launcher that starts 2 ranks for `--gpus 4` is an error, not a 2-rank line labelled otherwise."""
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--gaussians", "100000",
+                      "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extras"], 29629)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)

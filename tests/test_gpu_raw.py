@@ -162,3 +162,40 @@ def test_raw_rejects_missing_inputs(hip_device):
         _C.rasterize_gaussians_raw(z(3), z(4, 3), z(4, 1, 3), z(4, 15, 3), None, z(4, 3), z(4, 4), 1.0,
                                    cam.world_view_transform, cam.full_proj_transform, 0.4, 0.4, 64, 64, 3,
                                    cam.camera_center, False)
+
+
+def test_raw_path_under_view_streams_with_grad_output(hip_device):
+    """ViewStreams.run_view(..., grad_output=g) with the default direct=True used to CALL the autograd node
+    of the view's output -- only the compiled node of the standard operator is callable; render_raw's node belongs to a Python
+    autograd.Function ('...Backward' object is not callable).  Such views must go through the engine, and give the gradients
+    of the per-view backward."""
+    from luciddreamer_amd import config, parallel
+    from luciddreamer_amd.gaussian_renderer import render_raw
+    W, H, P = 256, 192, 6000
+    cam, cloud = h.box_setup(P, W, H, seed=11)
+    cams = [cam.to(hip_device)] * 4
+    bg = torch.tensor([0.2, 0.1, 0.3], device=hip_device)
+    gcol = synthetic.upstream_grad(H, W, seed=3).to(hip_device)
+
+    def run(piped):
+        pc = _pc(cloud, hip_device, 3)
+        config.set_fused_grad_accumulation(True)
+        try:
+            if piped:
+                pipe = parallel.ViewStreams(hip_device, 2)
+                pipe.begin_step()
+                for c in cams:
+                    pipe.run_view(lambda c=c: render_raw(c, pc, bg_color=bg)["render"], grad_output=gcol)
+                pipe.end_step()
+            else:
+                for c in cams:
+                    render_raw(c, pc, bg_color=bg)["render"].backward(gcol)
+            torch.cuda.synchronize()
+        finally:
+            config.set_fused_grad_accumulation(False)
+        return _grads(pc)
+
+    a, b = run(False), run(True)
+    for n in a:
+        assert a[n] is not None and np.abs(a[n]).max() > 0, n
+        assert np.abs(a[n] - b[n]).max() <= 1e-5 * np.abs(a[n]).max(), n
