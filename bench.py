@@ -467,6 +467,95 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     }
 
 
+def event_ms(fn, reps, warm=2):
+    """Average milliseconds per call of fn() by HIP events on the current stream (every kernel these helpers time is
+    launched on torch's current stream)."""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measure_f_rows(dev):
+    """SURVEY.md section 8f rows in numbers (outside every timed region of the headline): the fused L1 + DSSIM loss
+    (/root/reference/utils/loss.py:18-69) at 512^2 and 1080p, distCUDA2 (simple_knn.cu:186-221) at 1 M / 3 M points, the
+    one-launch Adam step and one prune of the parameter set (scene/gaussian_model.py:273-304: 6 parameters + 12 Adam
+    moments + 3 statistics) at C4 size.  HIP-event averages; bytes are the algorithmic minimum of each op, `frac` against 8 TB/s."""
+    out = {}
+    try:
+        from luciddreamer_amd.loss import l1_dssim_loss
+        for W, H in ((512, 512), (1920, 1080)):
+            gt = torch.rand(3, H, W, device=dev)
+            img = (0.7 * gt + 0.3 * torch.rand(3, H, W, device=dev)).requires_grad_(True)
+
+            def fb():
+                img.grad = None
+                l1_dssim_loss(img, gt, 0.2).backward()
+            ms = event_ms(fb, 30)
+            # forward reads image + target, backward reads both again and writes the gradient: 5 planes of 3 H W floats
+            b = 5 * 3 * H * W * 4
+            out[f"l1_dssim_fwd_bwd_{W}x{H}"] = {"us": round(ms * 1e3, 1), "algorithmic_bytes": b,
+                                               "frac": round(b / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+            del gt, img
+    except Exception as e:
+        out["l1_dssim_error"] = str(e)[:200]
+    try:
+        from simple_knn._C import distCUDA2
+        for P in (1_000_000, 3_000_000):
+            pts = torch.rand(P, 3, device=dev, generator=None) * 4.0 - 2.0
+            ms = event_ms(lambda: distCUDA2(pts), 5, warm=1)
+            out[f"dist2_{P // 1_000_000}M_points"] = {"ms": round(ms, 3), "what": "Morton order + 3-NN mean squared distance, lr_dist2"}
+            del pts
+    except Exception as e:
+        out["dist2_error"] = str(e)[:200]
+    try:
+        import torch.nn as nn
+        from luciddreamer_amd import densify as D
+        from luciddreamer_amd.optim import FusedAdam
+        P = 3_000_000
+
+        class M:
+            pass
+        m = M()
+        mk = lambda *sh: nn.Parameter(torch.randn(*sh, device=dev).requires_grad_(True))
+        m._xyz, m._features_dc, m._features_rest = mk(P, 3), mk(P, 1, 3), mk(P, 15, 3)
+        m._opacity, m._scaling, m._rotation = mk(P, 1), mk(P, 3), mk(P, 4)
+        m.percent_dense = 0.01
+        m.optimizer = FusedAdam([{"params": [getattr(m, a)], "lr": 1e-3, "name": n} for n, a in D.GROUP_ATTR.items()], lr=0.0, eps=1e-15)
+        for a in D.GROUP_ATTR.values():
+            getattr(m, a).grad = torch.zeros_like(getattr(m, a))
+        ms = event_ms(lambda: m.optimizer.step(), 10)
+        b = P * 59 * 4 * 7                                      # read parameter, gradient, two moments; write parameter, two moments
+        out["adam_step_3M"] = {"us": round(ms * 1e3, 1), "algorithmic_bytes": b, "frac": round(b / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
+        m.xyz_gradient_accum, m.denom = torch.zeros(P, 1, device=dev), torch.zeros(P, 1, device=dev)
+        m.max_radii2D = torch.zeros(P, device=dev)
+        D._store(m)
+        ts = []
+        for _ in range(4):
+            mask = torch.rand(m._xyz.shape[0], device=dev) < 0.05
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            D.prune_points(m, mask)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        rows = m._xyz.shape[0]
+        b = rows * (59 * 3 + 3) * 4 * 2                         # every surviving row of the 21 tensors read and written once
+        out["prune_5pct_of_3M"] = {"ms": round(min(ts[1:]) * 1e3, 3), "algorithmic_bytes": b,
+                                   "frac": round(b / min(ts[1:]) / (HBM_PEAK_GBS * 1e9), 4),
+                                   "what": "densify.prune_points: lr_select_rows over 6 parameters + 12 Adam moments + 3 statistics (wall clock, one call)"}
+        del m
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["densify_error"] = str(e)[:200]
+    return out
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: re-exec this command line under torch.distributed.run, one process per
     GPU of this node, backend nccl (= RCCL).  Fails loudly -- no N = 1 fallback -- when the node shows fewer than N devices
@@ -616,6 +705,7 @@ def main():
                                 "(parallel.ViewStreams); exact_mode: the same with the reference's host round trip per view; "
                                 "views_loss: the headline step with the fused L1+DSSIM loss formed inside; render_only: forward "
                                 "only, one stream, default configuration (the video renderer's loop)")
+    f_rows = measure_f_rows(dev) if extras else None
     cpu_baseline, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline, parity = run_cpu_baseline(wl)
@@ -666,6 +756,7 @@ def main():
             "sustained": sustained,
             "entry_points": entry_points,
             "other_workloads": other,
+            "f_rows": f_rows,
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -27,7 +27,7 @@ SOURCES = {
     "tilebin.hip": [],          # compaction, tile partition, per-tile sort
     # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
     "render_fwd.hip": ["-fno-slp-vectorize"],
-    "render_bwd.hip": ["-fno-slp-vectorize", "-mllvm", "-amdgpu-mfma-vgpr-form"],
+    "render_bwd.hip": ["-fno-slp-vectorize"],
     "gauss_bwd.hip": [],
     "knn.hip": [],
     # the separable window sums are long fma chains: packed f32 costs two issue slots plus the moves that form the pairs

@@ -55,7 +55,8 @@ struct GeomHeader {
     uint32_t num_instances;         // tile instances after exact tile culling (what is emitted and sorted)
     uint32_t bin_bound;             // instance count the binning buffer was laid out for (R or capacity)
     uint32_t num_compact;           // Gaussians that emit at least one instance (length of the compacted arrays)
-    uint32_t reserved[51];
+    uint32_t n_seg;                 // list segments beyond the first of every tile (BWD_SEG, below): entries of BinLayout::seg_list
+    uint32_t reserved[50];
     uint32_t sticky_overflow;       // set (never cleared by lr_forward) when a view overflowed: lr_views_accumulate / lr_views_check
     uint32_t reserved_tail[3];
 };
@@ -137,7 +138,7 @@ inline GeomLayout geom_layout(int P) {
     L.total = o;
     return L;
 }
-struct ImgLayout { size_t final_T, n_contrib, ranges, part_hist, bin_total, bin_start, big_queue, total; };
+struct ImgLayout { size_t final_T, n_contrib, ranges, part_hist, bin_total, bin_start, big_queue, tile_seg0, total; };
 inline ImgLayout img_layout(int W, int H) {
     ImgLayout L; size_t o = 0; size_t N = (size_t)W * H; if (N == 0) N = 1;
     size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y); if (T == 0) T = 1;
@@ -152,10 +153,19 @@ inline ImgLayout img_layout(int W, int H) {
     L.bin_total = o; o += align_up(bins * 4);
     L.bin_start = o; o += align_up(bins * 4);
     L.big_queue = o; o += align_up((bins + 1) * 4);
+    L.tile_seg0 = o; o += align_up(T * 4);           // first seg_list slot of each tile (written by the blend forward for tiles longer than BWD_SEG)
     L.total = o;
     return L;
 }
-struct BinLayout { size_t point_list, words, quad_hits, inst_gid, inst_grad, total; };
+// Segments of a tile's list.  The blend backward is a recursion along the list, but each stretch of BWD_SEG positions can
+// start on its own once it knows, per pixel, the transmittance in front of its deepest layer and the colour behind it: the
+// blend forward leaves both at every BWD_SEG-th position it reaches (`ckpt`: one float4 {T, colour still to come . rgb} per
+// pixel of the tile; pixel index = quadrant * 64 + lane of the forward) and lists the (tile, segment) pairs beyond each
+// tile's first segment in `seg_list` (slots reserved with one atomic per tile on GeomHeader::n_seg).  The backward runs one
+// workgroup per tile for the first segment and one per listed pair: long lists (hundreds to thousands of instances per
+// tile on small images and dense clouds) no longer make the kernel as slow as its longest tile.
+constexpr int BWD_SEG = 256;                 // = the staging round of the blend forward
+struct BinLayout { size_t point_list, words, quad_hits, inst_gid, inst_grad, seg_list, ckpt, total; };
 __host__ __device__ inline BinLayout bin_layout(long long R) {
     // point_list sits at offset 0: the tile-sorted list of EMISSION slots e; inst_gid[e] is the Gaussian and
     // inst_grad[e] the slot the blend backward writes that instance's nine partial sums to (one plain 48-byte
@@ -169,9 +179,13 @@ __host__ __device__ inline BinLayout bin_layout(long long R) {
     L.words = o;      L.quad_hits = o; o += align_up(Rz * 8);
     L.inst_gid = o;   o += align_up(Rz * 4);
     L.inst_grad = o;  o += align_up(Rz * sizeof(GradRec));
+    const size_t nseg = Rz / BWD_SEG + 2;                       // sum over the tiles of (length - 1) / BWD_SEG <= R / BWD_SEG
+    L.seg_list = o;   o += align_up(nseg * 8);                  // uint2 {tile, segment}
+    L.ckpt = o;       o += align_up(nseg * TILE_PIX * 16);       // float4 per pixel of the tile and listed segment
     L.total = o;
     return L;
 }
+inline long long bin_seg_capacity(long long R) { return (R > 0 ? R : 1) / BWD_SEG + 2; }
 
 // ---- exact tile culling ------------------------------------------------------------------------
 // A (Gaussian, tile) pair can only matter if some pixel of the tile reaches alpha >= 1/255, i.e. if
@@ -354,7 +368,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_PART_SCAN, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_PART_SCAN, TUNE_BWD_SEG, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): BLEND_QUAD = 4 waves per
@@ -389,11 +403,13 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
 }
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
-                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits, hipStream_t s);
+                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, hipStream_t s);
+// seg_bound: upper bound of GeomHeader::n_seg known to the host (bin_seg_capacity of the instance bound of the call)
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
-                       hipStream_t s);
+                       const uint32_t* tile_seg0, long long seg_bound, hipStream_t s);
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                       const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,

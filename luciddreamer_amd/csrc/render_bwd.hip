@@ -178,10 +178,11 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float qA, const float
 // reduction (three row sums, three LDS float atomics into a shared copy), kept selectable for A/B runs (tools/ab_bench.py).
 // Measured on MI355X, k_render_bwd single stream (profiles/r03b_ab_bwd_red_dpp_store.json): C3 100.6 -> 94.2 us, dense
 // 1 M cloud 526 -> 485 us, C5 shape (QUAD) 362 -> 324 us.
-// 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
-template <bool QUAD, bool MERGE, bool STRICT = false>
-__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 4 : 7, 8)))
-k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
+// One work item of the backward: segment `seg` of tile `tile` -- list positions [seg * BWD_SEG, (seg + 1) * BWD_SEG) -- or,
+// with seg < 0, the whole list.  ck_slot: the checkpoint the forward left at the segment's deep end (common.h BinLayout::ckpt).
+template <bool QUAD, bool MERGE, bool STRICT>
+__device__ __forceinline__ void render_bwd_item(const int tile, const int seg, const uint32_t ck_slot,
+             int W, int H, int gx, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -203,11 +204,6 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     __shared__ float s_acc[BATCH][NACC][12];
     __shared__ uint32_t s_wlast[NWAVES];
 
-    const int tile = blend_tile(tile_map, num_tiles);
-    if (tile < 0) return;
-    // async mode: a view that needed more tile instances than its binning buffer held (flag set by the forward's scan) is
-    // NOT differentiated -- its instance list is truncated.  k_gauss_bwd skips it as well: the view contributes zero.
-    if (hdr->overflow != 0u) return;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
     // this wave's box: 16x8 (pixel A left, pixel B right quadrant), or with QUAD the 8x8 quadrant (w&1, w>>1), pixel A only
@@ -221,11 +217,15 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     if (total == 0) return;
+    const int seg_lo = seg < 0 ? 0 : seg * BWD_SEG;                    // this item's stretch of the list
+    const int seg_hi = seg < 0 ? total : min(total, seg_lo + BWD_SEG);
+    if (seg_lo >= seg_hi) return;
     // R-dependent parts of the binning buffer, resolved on the device (the host does not know R here)
     const BinLayout BL = bin_layout((long long)hdr->bin_bound);
     const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
     const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
+    const float4* __restrict__ ck = reinterpret_cast<const float4*>(bin_base + BL.ckpt) + (size_t)ck_slot * TILE_PIX;
 
     BwdPix PA, PB;
     PA.pxf = (float)pxA; PB.pxf = (float)pxB;
@@ -236,6 +236,23 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     if (insB) { PB.dLr = dL_dpix[pixB]; PB.dLg = dL_dpix[N + pixB]; PB.dLb = dL_dpix[2 * N + pixB]; }
     PA.A = bg[0] * PA.dLr + bg[1] * PA.dLg + bg[2] * PA.dLb;       // background . dL/dpixel: the deepest layer
     PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
+    if (seg_hi < total) {
+        // The recursion starts in the middle of the list.  A pixel the forward was still blending at position seg_hi
+        // (last > seg_hi: it stopped later, or never) takes the forward's own T there and the colour still to come behind it
+        // from the checkpoint (render_fwd.hip); a pixel that had stopped by then starts as at the list's end (final T,
+        // background behind it): every position of this segment at or behind its `last` is skipped anyway.
+        const int qA = QUAD ? w : 2 * w;                         // quadrant of pixel A (pixel index of the checkpoint: quadrant * 64 + lane)
+        if (PA.last > (uint32_t)seg_hi) {
+            const float4 c = ck[qA * 64 + l];
+            PA.T = c.x;
+            PA.A = (c.y * PA.dLr + c.z * PA.dLg + c.w * PA.dLb) * __builtin_amdgcn_rcpf(c.x);
+        }
+        if (!QUAD && PB.last > (uint32_t)seg_hi) {
+            const float4 c = ck[(qA + 1) * 64 + l];
+            PB.T = c.x;
+            PB.A = (c.y * PB.dLr + c.z * PB.dLg + c.w * PB.dLb) * __builtin_amdgcn_rcpf(c.x);
+        }
+    }
     const uint32_t lastL = wave_max_u32(PA.last), lastR = QUAD ? 0u : wave_max_u32(PB.last);   // per quadrant
     const uint32_t wave_last = max(lastL, lastR);                   // nothing at or behind this matters to the wave
     // did the forward stop any pixel of this wave early?  (pixels outside the image carry T = 0 and dL = 0: whatever they step
@@ -262,10 +279,10 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     const bool merge_writer = (l16 & 3) == 0 && l16 < 12;
     const uint32_t merge_off = (uint32_t)(w * 12 + (l16 == 0 ? col_a : l16 == 8 ? col_a + 4 : 8 + row));
 
-    for (int base = 0; base < total; base += BATCH) {
-        // staged element i <-> list position pos = total-1-base-i (back to front)
-        const int cnt = min(BATCH, total - base);
-        const int pos_hi = total - 1 - base;             // position of staged element 0
+    for (int base = 0; base < seg_hi - seg_lo; base += BATCH) {
+        // staged element i <-> list position pos = seg_hi-1-base-i (back to front)
+        const int cnt = min(BATCH, seg_hi - seg_lo - base);
+        const int pos_hi = seg_hi - 1 - base;            // position of staged element 0
         const int pos_lo = pos_hi - (cnt - 1);
         if ((uint32_t)pos_lo >= tile_last) {             // whole batch lies behind every last contributor:
             if (tid < cnt) {                             // its instance slots still have to read as zero
@@ -394,8 +411,9 @@ k_render_bwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 // test (2.33 of 4 at C3).  The two rows of quadrants have their own dy, so the lane keeps the moments of the upper and the
 // lower pixel pair apart (D, D dx, D dx^2 each) and applies the dy factors to each pair before the reduction.  Single-wave
 // workgroups: 8160 of them at 1080p, no partner wave to wait for at the batch barriers.
-template <int BATCH>
-__device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
+template <int BATCH, bool STRICT>
+__device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, const uint32_t ck_slot,
+                  int W, int H, int gx, const uint2* __restrict__ ranges,
                   const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
                   const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -407,9 +425,6 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
     __shared__ uint32_t s_id[BATCH];
     __shared__ float s_acc[BATCH * 12]; // one wave, one copy: a candidate is met once per batch, so its sums are plain stores
 
-    const int tile = blend_tile(tile_map, num_tiles);
-    if (tile < 0) return;
-    if (hdr->overflow != 0u) return;
     const int tx = tile % gx, ty = tile / gx;
     const int l = threadIdx.x;
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y;
@@ -420,15 +435,19 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
     if (total == 0) return;
+    const int seg_lo = seg < 0 ? 0 : seg * BWD_SEG;                    // as render_bwd_item
+    const int seg_hi = seg < 0 ? total : min(total, seg_lo + BWD_SEG);
+    if (seg_lo >= seg_hi) return;
     const BinLayout BL = bin_layout((long long)hdr->bin_bound);
     const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
     const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
+    const float4* __restrict__ ck = reinterpret_cast<const float4*>(bin_base + BL.ckpt) + (size_t)ck_slot * TILE_PIX;
 
     // quadrant q = x half + 2 * y half (the forward's wave q): P0 upper left, P1 upper right, P2 lower left, P3 lower right
     BwdPix P0, P1, P2, P3;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    auto load_pixel = [&](BwdPix& p, int px, int py) {
+    auto load_pixel = [&](BwdPix& p, int px, int py, int q) {
         const bool ins = px < W && py < H;
         const size_t pix = (size_t)py * W + px;
         p.pxf = (float)px;
@@ -438,8 +457,13 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
         p.dLg = ins ? dL_dpix[N + pix] : 0.f;
         p.dLb = ins ? dL_dpix[2 * N + pix] : 0.f;
         p.A = bg0 * p.dLr + bg1 * p.dLg + bg2 * p.dLb;
+        if (seg_hi < total && p.last > (uint32_t)seg_hi) {          // as render_bwd_item: the forward's state at the segment's deep end
+            const float4 c = ck[q * 64 + l];
+            p.T = c.x;
+            p.A = (c.y * p.dLr + c.z * p.dLg + c.w * p.dLb) * __builtin_amdgcn_rcpf(c.x);
+        }
     };
-    load_pixel(P0, pxL, pyT); load_pixel(P1, pxR, pyT); load_pixel(P2, pxL, pyB); load_pixel(P3, pxR, pyB);
+    load_pixel(P0, pxL, pyT, 0); load_pixel(P1, pxR, pyT, 1); load_pixel(P2, pxL, pyB, 2); load_pixel(P3, pxR, pyB, 3);
     const uint32_t last0 = wave_max_u32(P0.last), last1 = wave_max_u32(P1.last);
     const uint32_t last2 = wave_max_u32(P2.last), last3 = wave_max_u32(P3.last);
     const uint32_t tile_last = max(max(last0, last1), max(last2, last3));
@@ -452,9 +476,9 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
     const bool merge_writer = (l16 & 3) == 0 && l16 < 12;
     const int merge_off = l16 == 0 ? col_a : l16 == 8 ? col_a + 4 : 8 + row;
 
-    for (int base = 0; base < total; base += BATCH) {
-        const int cnt = min(BATCH, total - base);
-        const int pos_hi = total - 1 - base;             // position of staged element 0 (back to front)
+    for (int base = 0; base < seg_hi - seg_lo; base += BATCH) {
+        const int cnt = min(BATCH, seg_hi - seg_lo - base);
+        const int pos_hi = seg_hi - 1 - base;            // position of staged element 0 (back to front)
         const int pos_lo = pos_hi - (cnt - 1);
         if ((uint32_t)pos_lo >= tile_last) {             // whole batch behind every last contributor: slots read as zero
             if (l < cnt) {
@@ -471,8 +495,8 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[l] = make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            *reinterpret_cast<float2*>(&s_q1[l]) = make_float2((-0.5f * LOG2E) * b.x, b.y);
+            s_q0[l] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            *reinterpret_cast<float2*>(&s_q1[l]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
             s_q2[l] = make_float4(b.z, b.w, c.x, 0.f);
             s_id[l] = e;
         }
@@ -504,14 +528,16 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             float tD = 0.f, tMx = 0.f, tMxx = 0.f, bD = 0.f, bMx = 0.f, bMxx = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
             const bool h0 = (m0 >> j) & 1ull, h1 = (m1 >> j) & 1ull, h2 = (m2 >> j) & 1ull, h3 = (m3 >> j) & 1ull;
             if (h0 || h1) {
-                const float Bd = gauss_bd(a.w, dysT), Cdd = gauss_cdd(b.x, dysT);                        // common.h gauss_power
-                if (h0) bwd_pixel<true, true, CHECK>(P0, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
-                if (h1) bwd_pixel<false, false, CHECK>(P1, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                float Bd, Cdd;
+                gauss_row<STRICT>(a.w, b.x, dysT, Bd, Cdd);                                              // common.h gauss_power
+                if (h0) bwd_pixel<true, true, CHECK, STRICT>(P0, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
+                if (h1) bwd_pixel<false, false, CHECK, STRICT>(P1, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, tD, tMx, tMxx, sR, sG, sB);
             }
             if (h2 || h3) {
-                const float Bd = gauss_bd(a.w, dysB), Cdd = gauss_cdd(b.x, dysB);
-                if (h2) bwd_pixel<true, false, CHECK>(P2, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
-                if (h3) bwd_pixel<false, false, CHECK>(P3, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                float Bd, Cdd;
+                gauss_row<STRICT>(a.w, b.x, dysB, Bd, Cdd);
+                if (h2) bwd_pixel<true, false, CHECK, STRICT>(P2, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
+                if (h3) bwd_pixel<false, false, CHECK, STRICT>(P3, a.z, a.w, b.x, Bd, Cdd, a.x, b.y, c.x, c.y, c.z, pos, bD, bMx, bMxx, sR, sG, sB);
             }
             // the dy factors, per pixel pair (a pair shares its row)
             const float t1 = dysT * tD, t2 = dysB * bD;
@@ -534,7 +560,8 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
             for (int k = 0; k < 12; k++) a9[k] = s_acc[l * 12 + k];
             const float4 q0 = s_q0[l]; const float2 q1 = *reinterpret_cast<const float2*>(&s_q1[l]);
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
-            const float ca = (-2.0f * LN2) * q0.z, cb = -LN2 * q0.w, cc = (-2.0f * LN2) * q1.x, o = q1.y;
+            const float ca = STRICT ? q0.z : (-2.0f * LN2) * q0.z, cb = STRICT ? q0.w : -LN2 * q0.w,
+                        cc = STRICT ? q1.x : (-2.0f * LN2) * q1.x, o = q1.y;
             const float sx = a9[0], sy = a9[1], h = -0.5f;          // as k_render_bwd: the sums carry the opacity factor
             const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;      // 1 ulp: the sum itself carries more
             float4* slot = inst_grad + 3 * (size_t)s_id[l];
@@ -551,380 +578,68 @@ __device__ __forceinline__ void render_bwd_tile(int W, int H, int gx, int num_ti
                       const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,                        \
                       char* __restrict__ bin_base, const GeomHeader* __restrict__ hdr, int force_check
 #define LR_BWD_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check
+// Work item of a workgroup.  The first `grid_tiles` workgroups take the FIRST segment of their tile (blend_tile: XCD-aware
+// tile map) -- or, with seg_on == 0, its whole list; the others walk the segments the forward listed (BinLayout::seg_list;
+// their number is on the device, so the launch covers an upper bound and a workgroup strides over what is there: any launch
+// size is correct).  Async mode: a view that needed more tile instances than its binning buffer held (flag set by the
+// forward's scan) is NOT differentiated -- its instance list is truncated.  k_gauss_bwd skips it as well.
+#define LR_BWD_KERNEL_BODY(ITEM)                                                                                            \
+    if (hdr->overflow != 0u) return;                                                                                        \
+    const bool listed = (int)blockIdx.x >= grid_tiles;                                                                      \
+    int tile = 0, seg = seg_on ? 0 : -1;                                                                                    \
+    uint32_t slot = 0u, e = 0u, n = 0u;                                                                                     \
+    const uint2* __restrict__ seg_list = nullptr;                                                                           \
+    if (!listed) {                                                                                                          \
+        tile = blend_tile(tile_map, num_tiles);                                                                             \
+        if (tile < 0) return;                                                                                               \
+        if (seg_on) slot = tile_seg0[tile];             /* read only by a tile longer than one segment, which wrote it */   \
+    } else {                                                                                                                \
+        seg_list = reinterpret_cast<const uint2*>(bin_base + bin_layout((long long)hdr->bin_bound).seg_list);               \
+        n = hdr->n_seg;                                                                                                     \
+        e = blockIdx.x - (uint32_t)grid_tiles;                                                                              \
+    }                                                                                                                       \
+    for (;;) {                                          /* ONE inlined copy of the item for both kinds of workgroup */      \
+        if (listed) {                                                                                                       \
+            if (e >= n) break;                                                                                              \
+            const uint2 ts = seg_list[e];               /* slot e holds segment ts.y; the checkpoint at its deep end: e + 1 */ \
+            tile = (int)ts.x; seg = (int)ts.y; slot = e + 1u;                                                               \
+        }                                                                                                                   \
+        ITEM(tile, seg, slot, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check); \
+        if (!listed) break;                                                                                                 \
+        e += gridDim.x - (uint32_t)grid_tiles;                                                                              \
+        lds_barrier();                                  /* the next item stages into the same LDS */                        \
+    }
+#define LR_BWD_SEG_PARAMS LR_BWD_PARAMS, const uint32_t* __restrict__ tile_seg0, int grid_tiles, int seg_on
+
+// 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
+template <bool QUAD, bool MERGE, bool STRICT = false>
+__global__ void __launch_bounds__(QUAD ? 256 : 128) __attribute__((amdgpu_waves_per_eu(QUAD ? 4 : 7, 8)))
+k_render_bwd(LR_BWD_SEG_PARAMS)
+{
+#define LR_ITEM render_bwd_item<QUAD, MERGE, STRICT>
+    LR_BWD_KERNEL_BODY(LR_ITEM)
+#undef LR_ITEM
+}
 // 64 VGPRs and 4.3 KB of LDS: 8 waves per SIMD, so the 8160 waves of a 1080p view are all resident at once (8192 slots).  The
 // tiles of a view carry nearly the same load (C3: 70 instances on average, 102 at most): with 7 per SIMD the last 992 waves
 // start when the first 7168 finish together and then run alone on their SIMDs, one instruction per ~5 cycles.
+template <bool STRICT>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_vgpr(64)))
-k_render_bwd_tile(LR_BWD_PARAMS) { render_bwd_tile<44>(LR_BWD_PASS); }
+k_render_bwd_tile(LR_BWD_SEG_PARAMS)
+{
+#define LR_ITEM render_bwd_tile<44, STRICT>
+    LR_BWD_KERNEL_BODY(LR_ITEM)
+#undef LR_ITEM
+}
 // the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
-k_render_bwd_tile7(LR_BWD_PARAMS) { render_bwd_tile<64>(LR_BWD_PASS); }
-
-// ---- the MFMA-transposed reduction (round 5) ---------------------------------------------------------------------------
-// What the shapes above pay per candidate and wave for the nine sums -- six lane swaps, six adds and seven DPP adds (88 issue
-// cycles at the measured costs, a third of the kernel) after five multiplies that form the moments -- is here two
-// v_mfma_f32_16x16x4_f32 pairs and eight FMAs, and the matrix pipe is otherwise idle.  Round 2 used the instruction as a
-// 64 -> 16 lane adder, one per term (nine per candidate: the matrix pipe became the limit, profiles/r02m).  Here it is used
-// as a TRANSPOSER.  With lane l = i + 16 k (i = l & 15, k = l >> 4) supplying A[i][k] = u[l] (the lane's datum) and
-// B[k][j] = b[l] (a lane CONSTANT), the result D[i][j] = sum_k u[i + 16 k] b_j(k) lands in lane (j, q = l >> 4), register r,
-// for i = 4 q + r: the datum's lane index i has moved into (row of lanes, register).  There a lane multiplies its four
-// registers by four more lane constants W_j(4 q + r) and adds them up (one v_mul + three v_fma): P[q][j].  A second MFMA with
-// A = 1 sums P over the four rows q:   total_j = sum_{i,k} u[i + 16 k] W_j(i) b_j(k),  for SIXTEEN different j at once --
-// every sum over the wave's 64 lanes of the datum times a weight that is separable in (i, k), or a sum of such.
-//   * the six moments of D = opacity G dL/dalpha are sums with weights 1, X, Y, X^2, XY, Y^2 in pixel coordinates relative
-//     to the centre of the wave's box (exact small half-integers; the flush shifts them to the splat's centre per staged
-//     element, once, in float): with x = i & 7, h = i >> 3, y = 2 k + h that is 14 separable columns (mf_w / mf_b below;
-//     9 when the lane owns one pixel).  A lane with several pixels (slots) chains their MFMAs through the accumulator
-//     operand: the slot's offset inside the box enters only through b.
-//   * the three colour sums weigh dchan = alpha T by the pixel's own dL/dpixel -- not separable; b = one-hot in k makes the
-//     first MFMA a pure transpose (column j = 4 t + k0 receives u[i + 16 k0]), the weights W are the pixel gradients
-//     transposed the same way once per kernel (by the same instruction), twelve columns.
-// The pixel step loses the five moment / colour multiplies; the candidate loop ends with one 26-lane ds_write into the wave's
-// own column block of the staged element; the flush reads back the blocks of the waves that met the element (the cull
-// predicate is recomputed there: nothing is zeroed).  Sums are fixed-order FMA chains inside the instruction: bit-repeatable.
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ v4f mfma4(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-constexpr int MF_NCM = 14;                  // moment columns of a lane with several pixels; 9 with one (no slot offsets)
-template <int NSLOT> struct MfCols {
-    static constexpr int n = NSLOT == 1 ? 9 : MF_NCM;
-    // physical column (lane of the column totals, word of the wave's block) -> logical column c0..c13 below
-    __device__ static constexpr int logical(int phys)
-    {
-        if (NSLOT != 1) return phys < MF_NCM ? phys : -1;
-        constexpr int map[9] = { 0, 1, 3, 6, 7, 8, 9, 12, 13 };
-        return phys < 9 ? map[phys] : -1;
-    }
-    __device__ static constexpr int phys(int logical_col)
-    {
-        if (NSLOT != 1) return logical_col;
-        constexpr int inv[14] = { 0, 1, -1, 2, -1, -1, 3, 4, 5, 6, -1, -1, 7, 8 };
-        return inv[logical_col];
-    }
-};
-// column j of the moment reduction: weight W_j(i) b_j(k); X = xc + sx, Y = Yk + yh with xc = (i & 7) - 3.5, yh = (i >> 3) - 0.5,
-// Yk = 2 k - 3 + sy, (sx, sy) = offset of the slot's 8x8 quadrant centre from the box centre
-//   M0 = c0   MX = c1 + c2   MXX = c3 + c4 + c5   MY = c6 + c7   MXY = c8 + c9 + c10 + c11   MYY = c12 + c13 + M0 / 4
-__device__ __forceinline__ float mf_w(int j, int i)
+k_render_bwd_tile7(LR_BWD_SEG_PARAMS)
 {
-    const float xc = (float)(i & 7) - 3.5f, yh = (float)(i >> 3) - 0.5f;
-    switch (j) {
-        case 0: case 2: case 5: case 6: case 10: case 12: return 1.f;
-        case 1: case 4: case 8: return xc;
-        case 3: return xc * xc;
-        case 7: case 11: case 13: return yh;
-        case 9: return xc * yh;
-        default: return 0.f;
-    }
-}
-__device__ __forceinline__ float mf_b(int j, int k, float sx, float sy)
-{
-    const float Yk = (float)(2 * k - 3) + sy;
-    switch (j) {
-        case 0: case 1: case 3: case 7: case 9: return 1.f;
-        case 2: case 11: return sx;
-        case 4: return 2.f * sx;
-        case 5: return sx * sx;
-        case 6: case 8: return Yk;
-        case 10: return sx * Yk;
-        case 12: return Yk * Yk;
-        case 13: return 2.f * Yk;
-        default: return 0.f;
-    }
+#define LR_ITEM render_bwd_tile<64, false>
+    LR_BWD_KERNEL_BODY(LR_ITEM)
+#undef LR_ITEM
 }
 
-// the pixel step of the shapes above without the lane sums: returns dop = opacity G dL/dalpha and dchan = alpha T
-template <bool CHECK_LAST, bool STRICT>
-__device__ __forceinline__ void bwd_pixel_mf(BwdPix& p, const float qA, const float qB, const float qC, const float r0, const float r1,
-                                             const float gx, const float op, const float cr, const float cg, const float cb,
-                                             const uint32_t pos, float& dop, float& dchan)
-{
-    const float dx = gx - p.pxf;
-    float power;
-    const float t = op * gauss_weight<STRICT>(qA, qB, qC, r0, r1, dx, power);
-    const bool v = (!CHECK_LAST || pos < p.last) && power <= 0.0f && t >= 1.0f / 255.0f;
-    const float tm = v ? t : 0.f;
-    const float alpha = fminf(0.99f, tm);
-    const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-    p.T = p.T * rinv;
-    dchan = alpha * p.T;
-    const float d = __builtin_fmaf(cb, p.dLb, __builtin_fmaf(cg, p.dLg, __builtin_fmaf(cr, p.dLr, -p.A)));
-    dop = tm * (d * p.T);
-    p.A = __builtin_fmaf(alpha, d, p.A);
-}
-
-// NSLOT pixels per lane: 1 = four waves per tile, a wave owns an 8x8 quadrant (small images); 2 = two waves, a wave owns a
-// 16x8 half tile; 4 = one wave per tile.  Slot s of a lane is the pixel (l & 7, l >> 3) of quadrant s of the wave's box.
-// CMF: colour sums through the matrix pipe as well (false: lane sums + swaps / DPP adds, three terms).
-template <int NSLOT, bool CMF, bool STRICT, int BATCH>
-__device__ __forceinline__ void render_bwd_mf(LR_BWD_PARAMS)
-{
-    constexpr int NWAVES = 4 / NSLOT;
-    constexpr int NCC = CMF ? 12 : 3;                  // colour columns
-    constexpr int NCM = MfCols<NSLOT>::n;              // moment columns
-    constexpr int NACC = NCM + NCC;                    // floats a wave leaves per staged element it met
-    constexpr int STRIDE = (NWAVES * NACC) | 1;        // odd: the flush (lane = staged element) reads without bank conflicts
-    __shared__ float4 s_q0[BATCH];      // as k_render_bwd
-    __shared__ float4 s_q1[BATCH];
-    __shared__ float4 s_q2[BATCH];
-    __shared__ uint32_t s_id[BATCH];
-    __shared__ uint32_t s_hit[BATCH];
-    __shared__ float s_acc[BATCH * STRIDE];
-    __shared__ uint32_t s_lastq[4];     // deepest last contributor per quadrant of the tile (q = x half + 2 * y half)
-
-    const int tile = blend_tile(tile_map, num_tiles);
-    if (tile < 0) return;
-    if (hdr->overflow != 0u) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    // the wave's box and its first quadrant
-    const int q0 = NSLOT == 1 ? w : NSLOT == 2 ? 2 * w : 0;
-    const int bx = tx * TILE_X + (q0 & 1) * 8, by = ty * TILE_Y + (q0 >> 1) * 8;
-    const size_t N = (size_t)W * H;
-
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-    if (total == 0) return;
-    const BinLayout BL = bin_layout((long long)hdr->bin_bound);
-    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
-    float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
-    const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
-
-    BwdPix P[NSLOT];
-    uint32_t lastq[NSLOT];
-    bool stopped = false;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) {
-        const int px = bx + (s & 1) * 8 + (l & 7), py = by + (s >> 1) * 8 + (l >> 3);
-        const bool ins = px < W && py < H;
-        const size_t pix = (size_t)py * W + px;
-        P[s].pxf = (float)px;
-        P[s].T = ins ? final_Ts[pix] : 0.f;
-        P[s].last = ins ? n_contrib[pix] : 0u;
-        P[s].dLr = ins ? dL_dpix[pix] : 0.f;
-        P[s].dLg = ins ? dL_dpix[N + pix] : 0.f;
-        P[s].dLb = ins ? dL_dpix[2 * N + pix] : 0.f;
-        P[s].A = bg0 * P[s].dLr + bg1 * P[s].dLg + bg2 * P[s].dLb;
-        lastq[s] = wave_max_u32(P[s].last);
-        stopped = stopped || (ins && P[s].last < (uint32_t)total);
-        if (l == 0) s_lastq[q0 + s] = lastq[s];
-    }
-    const float pyf0 = (float)(by + (l >> 3)), pyf1 = pyf0 + 8.0f;          // the lane's row in the upper / lower quadrants
-    const bool any_stopped = force_check != 0 || __ballot(stopped) != 0ull;
-    const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
-    const float ddely_dy = (float)(0.5 * H);
-
-    // lane constants of the reduction.  As the B operand of the first MFMA this lane is (k = l >> 4, column j = l & 15); as a
-    // holder of its result it is (column j = l & 15, row q = l >> 4) with registers r <-> i = 4 q + r.
-    const int cj = l & 15, cq = l >> 4;
-    float b1m[NSLOT];
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++)
-        b1m[s] = mf_b(MfCols<NSLOT>::logical(cj), cq, NSLOT == 1 ? 0.f : ((s & 1) ? 4.f : -4.f), NSLOT == 4 ? ((s >> 1) ? 4.f : -4.f) : 0.f);
-    float Wm[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) Wm[r] = mf_w(MfCols<NSLOT>::logical(cj), 4 * cq + r);
-    const float b1c = (cj < 12 && cq == (cj & 3)) ? 1.f : 0.f;
-    float Wc[CMF ? NSLOT : 1][4];
-    if (CMF) {
-        // transposed pixel gradients: Wc[s][r] of lane (j, q) = dL_{t = j >> 2} of the pixel of lane (4 q + r) + 16 (j & 3)
-        const float b1t = (cq == (cj & 3)) ? 1.f : 0.f;
-        const v4f z = { 0.f, 0.f, 0.f, 0.f };
-#pragma unroll
-        for (int s = 0; s < NSLOT; s++) {
-            const v4f tr = mfma4(P[s].dLr, b1t, z), tg = mfma4(P[s].dLg, b1t, z), tb = mfma4(P[s].dLb, b1t, z);
-#pragma unroll
-            for (int r = 0; r < 4; r++) Wc[s][r] = cj < 4 ? tr[r] : cj < 8 ? tg[r] : cj < 12 ? tb[r] : 0.f;
-        }
-    }
-    // the store that ends a candidate: moments from lanes 0-13, colours from lanes 16-27 (CMF) / the row leaders 16, 32, 48
-    const bool writer = CMF ? (cq == 0 ? cj < NCM : (cq == 1 && cj < 12)) : (cq == 0 ? cj < NCM : cj == 0);
-    const int woff = w * NACC + (CMF ? (cq == 0 ? cj : NCM + cj) : (cq == 0 ? cj : NCM + cq - 1));
-    const bool row0 = cq == 0;
-
-    lds_barrier();
-    uint32_t tile_last = 0;
-#pragma unroll
-    for (int i = 0; i < 4; i++) tile_last = max(tile_last, s_lastq[i]);
-    uint32_t wave_last = 0;
-#pragma unroll
-    for (int s = 0; s < NSLOT; s++) wave_last = max(wave_last, lastq[s]);
-
-    for (int base = 0; base < total; base += BATCH) {
-        const int cnt = min(BATCH, total - base);
-        const int pos_hi = total - 1 - base;             // position of staged element 0 (back to front)
-        const int pos_lo = pos_hi - (cnt - 1);
-        if ((uint32_t)pos_lo >= tile_last) {             // whole batch behind every last contributor: slots read as zero
-            if (tid < cnt) {
-                float4* slot = inst_grad + 3 * (size_t)point_list[range.x + (pos_hi - tid)];
-                slot[0] = make_float4(0.f, 0.f, 0.f, 0.f); slot[1] = slot[0]; slot[2] = slot[0];
-            }
-            continue;
-        }
-        lds_barrier();
-        if (tid < cnt) {
-            const uint32_t e = point_list[range.x + (pos_hi - tid)];
-            s_hit[tid] = quad_hits[range.x + (pos_hi - tid)];
-            const uint32_t id = inst_gid[e];
-            const float4* g = reinterpret_cast<const float4*>(rec + id);
-            const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            *reinterpret_cast<float2*>(&s_q1[tid]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
-            s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
-            s_id[tid] = e;
-        }
-        lds_barrier();
-
-        for (int sb = 0; sb < cnt; sb += 64) {
-            // CULL (as k_render_bwd): the forward's quadrant tests, each quadrant with its own deepest last contributor
-            uint64_t m[NSLOT];
-            {
-                const int j = sb + l;
-                const uint32_t pos = (uint32_t)(pos_hi - j);
-                const uint32_t h = (j < cnt && pos < wave_last) ? (s_hit[j] >> (8 * q0)) : 0u;
-#pragma unroll
-                for (int s = 0; s < NSLOT; s++) m[s] = __ballot(pos < lastq[s] && ((h >> (8 * s)) & 0xffu) != 0u);
-            }
-            uint64_t mask = m[0];
-#pragma unroll
-            for (int s = 1; s < NSLOT; s++) mask |= m[s];
-            auto walk = [&](auto chk) {
-            constexpr bool CHECK = decltype(chk)::value;
-            while (mask) {
-                const int k = __ffsll((long long)mask) - 1;       // staged order is already back to front
-                mask &= mask - 1;
-                const int j = sb + k;
-                const uint32_t pos = (uint32_t)(pos_hi - j);
-                const float4 a = s_q0[j];
-                const float2 b = *reinterpret_cast<const float2*>(&s_q1[j]);   // Cp, opacity
-                const float4 c = s_q2[j];
-                v4f accm = { 0.f, 0.f, 0.f, 0.f };
-                float Pc = 0.f, sR = 0.f, sG = 0.f, sB = 0.f;
-#pragma unroll
-                for (int half = 0; half < (NSLOT == 4 ? 2 : 1); half++) {        // slots of one row of quadrants share dy
-                    const int s0 = 2 * half;
-                    if constexpr (NSLOT == 4) {
-                        if (!(((m[s0] | m[s0 + 1]) >> k) & 1ull)) continue;
-                    }
-                    const float dys = a.y - (half ? pyf1 : pyf0);
-                    float r0, r1;
-                    gauss_row<STRICT>(a.w, b.x, dys, r0, r1);
-#pragma unroll
-                    for (int u = 0; u < (NSLOT >= 2 ? 2 : 1); u++) {
-                        const int s = s0 + u;
-                        bool hit = true;
-                        if constexpr (NSLOT > 1) hit = (m[s] >> k) & 1ull;
-                        if (hit) {
-                            float dop, dchan;
-                            bwd_pixel_mf<CHECK, STRICT>(P[s], a.z, a.w, b.x, r0, r1, a.x, b.y, c.x, c.y, c.z, pos, dop, dchan);
-                            accm = mfma4(dop, b1m[s], accm);
-                            if (CMF) {
-                                const v4f z = { 0.f, 0.f, 0.f, 0.f };
-                                const v4f t = mfma4(dchan, b1c, z);
-                                Pc = __builtin_fmaf(Wc[s][3], t[3], __builtin_fmaf(Wc[s][2], t[2],
-                                     __builtin_fmaf(Wc[s][1], t[1], __builtin_fmaf(Wc[s][0], t[0], Pc))));
-                            } else {
-                                sR = __builtin_fmaf(dchan, P[s].dLr, sR);
-                                sG = __builtin_fmaf(dchan, P[s].dLg, sG);
-                                sB = __builtin_fmaf(dchan, P[s].dLb, sB);
-                            }
-                        }
-                    }
-                }
-                const float Pm = __builtin_fmaf(Wm[3], accm[3], __builtin_fmaf(Wm[2], accm[2], __builtin_fmaf(Wm[1], accm[1], Wm[0] * accm[0])));
-                const v4f z = { 0.f, 0.f, 0.f, 0.f };
-                float val = mfma4(1.0f, Pm, z)[0];                 // every row of lanes: column totals, lane j <-> column j
-                if (CMF) {
-                    const float vc = mfma4(1.0f, Pc, z)[0];
-                    val = row0 ? val : vc;
-                } else {
-                    // three lane sums over the wave: two swap levels leave R | B | G | B in the rows, a row sum finishes
-                    // three lane sums over the wave: two swap levels leave B | R | G | B in the four rows of lanes (as
-                    // reduce8), a row sum finishes; rows 1-3 hand R, G, B to their first lane
-                    float sB2 = sB;
-                    asm volatile("s_nop 1\n\t"
-                                 "v_permlane32_swap_b32 %0, %1\n\t"
-                                 "v_permlane32_swap_b32 %2, %3\n\t"
-                                 "v_add_f32 %0, %0, %1\n\t"
-                                 "v_add_f32 %2, %2, %3\n\t"
-                                 "s_nop 0\n\t"
-                                 "v_permlane16_swap_b32 %0, %2\n\t"
-                                 "v_add_f32 %0, %0, %2\n\t"
-                                 "s_nop 1"
-                                 : "+v"(sB), "+v"(sG), "+v"(sR), "+v"(sB2));
-                    const float rc = row_sum(sB);
-                    val = row0 ? val : rc;
-                }
-                int jo = j * STRIDE;
-                asm volatile("" : "+s"(jo));
-                if (writer) s_acc[jo + woff] = val;
-            }
-            };
-            if constexpr (NSLOT == 4) walk(BoolTag<true>{});      // one copy of the loop (registers), as the TILE shape
-            else { if (any_stopped) walk(BoolTag<true>{}); else walk(BoolTag<false>{}); }
-        }
-        lds_barrier();
-        if (tid < cnt) {
-            const uint32_t pos = (uint32_t)(pos_hi - tid);
-            const uint32_t hits = s_hit[tid];
-            const float4 q0v = s_q0[tid]; const float2 q1v = *reinterpret_cast<const float2*>(&s_q1[tid]);
-            float a9[9];
-#pragma unroll
-            for (int k = 0; k < 9; k++) a9[k] = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < NWAVES; ww++) {
-                // did wave ww meet this element?  (the cull predicate of the candidate loop, restated per quadrant)
-                const int wq0 = NSLOT == 1 ? ww : NSLOT == 2 ? 2 * ww : 0;
-                bool met = false;
-#pragma unroll
-                for (int s = 0; s < NSLOT; s++) met = met || (pos < s_lastq[wq0 + s] && ((hits >> (8 * (wq0 + s))) & 0xffu) != 0u);
-                if (!met) continue;
-                const float* col = &s_acc[tid * STRIDE + ww * NACC];
-                using MC = MfCols<NSLOT>;
-                const float M0 = col[0];
-                float MX = col[MC::phys(1)], MXX = col[MC::phys(3)], MY = col[MC::phys(6)] + col[MC::phys(7)],
-                      MXY = col[MC::phys(8)] + col[MC::phys(9)], MYY = col[MC::phys(12)] + col[MC::phys(13)];
-                if constexpr (NSLOT >= 2) { MX += col[2]; MXX += col[4] + col[5]; MXY += col[10] + col[11]; }
-                MYY = __builtin_fmaf(0.25f, M0, MYY);
-                // box centre of wave ww; the moments move from there to the splat's centre (d = mean - pixel)
-                const float cx = (float)(tx * TILE_X + (wq0 & 1) * 8) + (NSLOT == 1 ? 3.5f : 7.5f);
-                const float cy = (float)(ty * TILE_Y + (wq0 >> 1) * 8) + (NSLOT == 4 ? 7.5f : 3.5f);
-                const float gxq = q0v.x - cx, gyq = q0v.y - cy;
-                const float Sx = gxq * M0 - MX, Sy = gyq * M0 - MY;
-                a9[0] += Sx;
-                a9[1] += Sy;
-                a9[2] += gxq * Sx - (gxq * MX - MXX);
-                a9[3] += gxq * Sy - (gyq * MX - MXY);
-                a9[4] += gyq * Sy - (gyq * MY - MYY);
-                a9[5] += M0;
-                if (CMF) {
-                    a9[6] += (col[NCM + 0] + col[NCM + 1]) + (col[NCM + 2] + col[NCM + 3]);
-                    a9[7] += (col[NCM + 4] + col[NCM + 5]) + (col[NCM + 6] + col[NCM + 7]);
-                    a9[8] += (col[NCM + 8] + col[NCM + 9]) + (col[NCM + 10] + col[NCM + 11]);
-                } else {
-                    a9[6] += col[NCM + 0];
-                    a9[7] += col[NCM + 1];
-                    a9[8] += col[NCM + 2];
-                }
-            }
-            const float ca = STRICT ? q0v.z : (-2.0f * LN2) * q0v.z, cb = STRICT ? q0v.w : -LN2 * q0v.w,
-                        cc = STRICT ? q1v.x : (-2.0f * LN2) * q1v.x, o = q1v.y;
-            const float sx = a9[0], sy = a9[1], hh = -0.5f;
-            const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;
-            float4* slot = inst_grad + 3 * (size_t)s_id[tid];
-            slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, hh * a9[2], hh * a9[3]);
-            slot[1] = make_float4(hh * a9[4], dopac, a9[6], a9[7]);
-            slot[2] = make_float4(a9[8], 0.f, 0.f, 0.f);
-        }
-    }
-}
-
-
-// (registers: the compiler's own budget; LDS per workgroup 64 x (3 x 16 + 8) + 64 x STRIDE x 4 bytes)
-template <int NSLOT, bool CMF, bool STRICT>
-__global__ void __launch_bounds__(NSLOT == 1 ? 256 : NSLOT == 2 ? 128 : 64)
-k_render_bwd_mf(LR_BWD_PARAMS) { render_bwd_mf<NSLOT, CMF, STRICT, 64>(LR_BWD_PASS); }
 #undef LR_BWD_PARAMS
 #undef LR_BWD_PASS
 
@@ -960,14 +675,13 @@ int blend_shape(int num_tiles)
     // instead of per half tile reached, the dy bookkeeping it adds is plain multiplies), but its 8160 waves -- all resident
     // at once, all in the same phase -- expose their staging latencies together when the kernel has the GPU to itself.  So:
     // one wave per tile when other views' kernels fill those gaps, the 2-wave shape for a lone view.
-    // (strict mode -- lr_tune_set("strict", 1) -- exists in the 2-wave and 4-wave shapes)
-    return (views_in_flight() >= 2 && tune_get(TUNE_STRICT) <= 0) ? BLEND_TILE : BLEND_HALF;
+    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_HALF;
 }
 
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
-                       hipStream_t s)
+                       const uint32_t* tile_seg0, long long seg_bound, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
@@ -988,32 +702,29 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
     int shape = blend_shape(num_tiles);
     const bool strict = tune_get(TUNE_STRICT) > 0;
-    // lr_tune_set("bwd_red", 5 / 6): the MFMA-transposed reduction, colour sums through the matrix pipe too / by lane swaps
-    if (red == 5 || red == 6) {
-        const int threads = shape == BLEND_QUAD ? 256 : shape == BLEND_TILE ? 64 : 128;
-#define LR_MF(NS, CMF)                                                                                                       \
-        do { if (strict) hipLaunchKernelGGL((k_render_bwd_mf<NS, CMF, true>), dim3(grid), dim3(threads), 0, s, LR_BWD_ARGS);    \
-             else hipLaunchKernelGGL((k_render_bwd_mf<NS, CMF, false>), dim3(grid), dim3(threads), 0, s, LR_BWD_ARGS); } while (0)
-        if (shape == BLEND_QUAD) { if (red == 5) LR_MF(1, true); else LR_MF(1, false); }
-        else if (shape == BLEND_TILE) { if (red == 5) LR_MF(4, true); else LR_MF(4, false); }
-        else { if (red == 5) LR_MF(2, true); else LR_MF(2, false); }
-#undef LR_MF
-        return;
-    }
-    if (strict && shape == BLEND_TILE) shape = BLEND_HALF;
-    if (strict) {
-        if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
-        else hipLaunchKernelGGL((k_render_bwd<false, true, true>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
-    } else if (shape == BLEND_TILE) {
-        if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
-        else hipLaunchKernelGGL(k_render_bwd_tile, dim3(grid), dim3(64), 0, s, LR_BWD_ARGS);
+    // Segments (common.h BWD_SEG): on by default; lr_tune_set("bwd_seg", 0) / LR_BWD_SEG=0 = one workgroup walks a tile's
+    // whole list (rounds 1-4; A/B partner).  The launch adds workgroups for the listed segments up to the bound the host
+    // knows, capped (a workgroup strides over the list, so the cap costs nothing but balance on absurdly long lists).
+    static const int forced_seg = [] { const char* e = getenv("LR_BWD_SEG"); return e ? atoi(e) : -1; }();
+    const int seg_on = (tune_get(TUNE_BWD_SEG) >= 0 ? tune_get(TUNE_BWD_SEG) : (forced_seg >= 0 ? forced_seg : 1)) != 0 ? 1 : 0;
+    const int extra = seg_on ? (int)(seg_bound < 1 ? 1 : seg_bound > 262144 ? 262144 : seg_bound) : 0;
+    const dim3 g(grid + extra);
+#define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, grid, seg_on
+    if (shape == BLEND_TILE) {
+        if (strict) hipLaunchKernelGGL(k_render_bwd_tile<true>, g, dim3(64), 0, s, LR_SEG_ARGS);
+        else if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, g, dim3(64), 0, s, LR_SEG_ARGS);
+        else hipLaunchKernelGGL(k_render_bwd_tile<false>, g, dim3(64), 0, s, LR_SEG_ARGS);
+    } else if (strict) {
+        if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, true, true>), g, dim3(256), 0, s, LR_SEG_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<false, true, true>), g, dim3(128), pad, s, LR_SEG_ARGS);
     } else if (shape == BLEND_QUAD) {
-        if (merge) hipLaunchKernelGGL((k_render_bwd<true, true>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
-        else hipLaunchKernelGGL((k_render_bwd<true, false>), dim3(grid), dim3(256), 0, s, LR_BWD_ARGS);
+        if (merge) hipLaunchKernelGGL((k_render_bwd<true, true>), g, dim3(256), 0, s, LR_SEG_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<true, false>), g, dim3(256), 0, s, LR_SEG_ARGS);
     } else {
-        if (merge) hipLaunchKernelGGL((k_render_bwd<false, true>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
-        else hipLaunchKernelGGL((k_render_bwd<false, false>), dim3(grid), dim3(128), pad, s, LR_BWD_ARGS);
+        if (merge) hipLaunchKernelGGL((k_render_bwd<false, true>), g, dim3(128), pad, s, LR_SEG_ARGS);
+        else hipLaunchKernelGGL((k_render_bwd<false, false>), g, dim3(128), pad, s, LR_SEG_ARGS);
     }
+#undef LR_SEG_ARGS
 #undef LR_BWD_ARGS
 }
 

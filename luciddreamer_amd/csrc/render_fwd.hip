@@ -76,13 +76,16 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
              const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-             float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits)
+             float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
+             GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,
+             uint32_t* __restrict__ tile_seg0)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
     __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity, depth, qmax (cull threshold, x log2 e)
     __shared__ float4 s_q2[BATCH];      // r, g, b, -
     __shared__ float2 s_q3[BATCH];      // -b/c, -b/a (edge minimiser slopes for box_hit)
     __shared__ int s_wdone[NWAVES];
+    __shared__ uint32_t s_seg0;
 
     const int tile = blend_tile(tile_map, num_tiles);
     if (tile < 0) return;
@@ -101,12 +104,31 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     uint64_t done = __builtin_amdgcn_ballot_w64(!inside);             // lane mask of finished pixels (all 64 lanes are live)
     bool wave_done = done == ~0ull;
 
+    // A list longer than BWD_SEG is cut into segments for the backward (common.h BinLayout::seg_list / ckpt): one atomic
+    // reserves the tile's slots, the (tile, segment) pairs are listed, and at the top of every later staging round the
+    // waves still blending leave {T, colour so far} of their pixels -- turned into {T, colour still to come} at the end
+    static_assert(BATCH == BWD_SEG, "a staging round of the forward is one segment of the backward");
+    const int n_seg = total > 0 ? (total - 1) / BWD_SEG : 0;
+    uint32_t seg0 = 0;
+    int n_ck = 0;                                                     // checkpoints this wave has written (segments 1 .. n_ck)
+    if (n_seg > 0) {
+        if (tid == 0) { s_seg0 = atomicAdd(&hdr->n_seg, (uint32_t)n_seg); tile_seg0[tile] = s_seg0; }
+        lds_barrier();
+        seg0 = s_seg0;
+        for (int g = 1 + tid; g <= n_seg; g += THREADS) seg_list[seg0 + g - 1] = make_uint2((uint32_t)tile, (uint32_t)g);
+    }
+
     for (int base = 0; base < total; base += BATCH) {
         // all quadrants finished?  (also the barrier that protects the LDS planes of the previous batch)
         if (l == 0) s_wdone[w] = wave_done ? 1 : 0;
         lds_barrier();
         if (s_wdone[0] + s_wdone[1] + s_wdone[2] + s_wdone[3] == NWAVES) break;
         const int cnt = min(BATCH, total - base);
+        if (base > 0 && !wave_done) {
+            // every pixel of a wave that is done stopped in front of this position: the backward starts those from final_T
+            ckpt[(size_t)(seg0 + n_ck) * TILE_PIX + tid] = make_float4(A.T, A.Cr, A.Cg, A.Cb);
+            n_ck++;
+        }
         if (tid < cnt) {
             const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
             const float4* g = reinterpret_cast<const float4*>(rec + id);
@@ -156,6 +178,15 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
         }
     }
 
+    if (n_ck > 0) {
+        // colour still to come behind each checkpoint = final colour (background included) - colour so far
+        const float fr = A.Cr + A.T * bg[0], fg = A.Cg + A.T * bg[1], fb = A.Cb + A.T * bg[2];
+        for (int g = 0; g < n_ck; g++) {
+            float4* c = ckpt + (size_t)(seg0 + g) * TILE_PIX + tid;
+            const float4 v = *c;
+            *c = make_float4(v.x, fr - v.y, fg - v.z, fb - v.w);
+        }
+    }
     if (inside) {
         const size_t N = (size_t)W * H;
         const size_t pix = (size_t)py * W + px;
@@ -172,7 +203,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
-                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits, hipStream_t s)
+                       uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
@@ -180,10 +212,10 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const int grid = ((num_tiles + 7) / 8) * 8;
     if (tune_get(TUNE_STRICT) > 0)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
-                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
+                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0);
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
-                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits);
+                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0);
 }
 
 }  // namespace lr

@@ -138,6 +138,7 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
         hdr->num_instances = total;             // after exact tile culling: what is binned
         hdr->bin_bound = capacity != 0 ? capacity : total;   // what the binning buffer is laid out for
         hdr->num_compact = run_c;
+        hdr->n_seg = 0u;                        // the blend forward reserves its list segments on it
         if (over) hdr->sticky_overflow = 1u;
         if (log_slot != nullptr) {
             // the library's forward log (host-visible memory, api.hip ForwardLog): the header words first, the tag last,

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan", "bwd_seg"):
         _lib.tune_set(k, -1)
 
 
@@ -296,3 +296,38 @@ def test_ranges_reserved_by_the_count_kernel_give_the_lists_of_the_scanned_rows(
         assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
         for k in a["grads"]:
             assert np.array_equal(a["grads"][k], b["grads"][k]), k
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])        # 2 waves x 2 pixels, 4 waves x 1 pixel, 1 wave x 4 pixels per tile
+@pytest.mark.parametrize("P,W,H,scale_mult", [(150_000, 256, 192, 1.0), (40_000, 320, 208, 5.0)])
+def test_list_segments_give_the_gradients_of_the_whole_list(hip_device, shape, P, W, H, scale_mult):
+    """Lists longer than 256 instances are differentiated in segments, one workgroup each, starting from the state the forward
+    left at every 256th position (common.h BWD_SEG; render_fwd.hip checkpoints): T there is the forward's own, the colour behind
+    it the final colour minus the colour so far.  lr_tune_set("bwd_seg", 0) = one workgroup walks the whole list (rounds 1-4).
+    Same layers differentiated, same per-instance slots written: the gradients agree to float rounding, both agree with the
+    oracle, and both are repeatable bit for bit.  Dense clouds on small images: hundreds to thousands of instances per tile,
+    most pixels stopped early in the second scene."""
+    cam, cloud = hp.box_setup(P, W, H, seed=13, scale_mult=scale_mult)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.3, 0.1, 0.2])
+    _lib.tune_set("blend_quad", shape)
+    try:
+        outs = []
+        for seg in (0, 1, 1):
+            _lib.tune_set("bwd_seg", seg)
+            outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
+    finally:
+        _lib.tune_set("bwd_seg", -1)
+        _lib.tune_set("blend_quad", -1)
+    whole, segs, again = outs
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    R = int(ref["num_rendered"])
+    assert R > 256 * 3 * ((W + 15) // 16) * ((H + 15) // 16)          # several segments per tile on average (before exact culling)
+    assert np.array_equal(whole["color"], segs["color"])
+    for k in whole["grads"]:
+        a, b = whole["grads"][k], segs["grads"][k]
+        scale = float(np.abs(a).max())
+        assert float(np.abs(a - b).max()) <= 4e-6 * scale, (k, float(np.abs(a - b).max()) / max(scale, 1e-30))
+        assert np.array_equal(segs["grads"][k], again["grads"][k]), k
+    assert all(float(np.abs(whole["grads"][k]).max()) > 0 for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+    hp.compare_grads_by_row(segs, ref, P)
