@@ -294,10 +294,14 @@ def read_counter_csv(directory, counter, acc):
     return rows
 
 
-def pick_kernel(counters, stage):
-    """The counter record of the kernel a single-stream stage timing belongs to: k_<stage><...> before k_<stage>_other (the
-    2-wave k_render_bwd<...>, not k_render_bwd_tile, which only the multi-stream legs launch) -- '<' sorts before '_'."""
-    return next((counters[k] for k in sorted(counters) if isinstance(counters[k], dict) and k.startswith("k_" + stage)), {})
+def pick_kernel(counters, stage, prefer=None):
+    """The counter record of the kernel a stage timing belongs to.  `prefer`: a name prefix to take first (the blend backward
+    has several shapes: "k_render_bwd_tile" is what the multi-stream headline launches at 1080p, "k_render_bwd<" what a lone
+    view gets); otherwise k_<stage><...> before k_<stage>_other ('<' sorts before '_').  Returns (name, record)."""
+    names = [k for k in sorted(counters) if isinstance(counters[k], dict) and k.startswith("k_" + stage)]
+    if prefer:
+        names = [k for k in names if k.startswith(prefer)] + [k for k in names if not k.startswith(prefer)]
+    return (names[0], counters[names[0]]) if names else (None, {})
 
 
 def live_pmc_counters(timeout_s=90):
@@ -344,17 +348,39 @@ def live_pmc_counters(timeout_s=90):
             "(child: bench.py --views 4 --steps 1 --warmup 1 --no-extras)")
 
 
-def roofline_leg(wl, api, exact, steps, world, dev, value, args):
-    """The same steps again on ONE stream so that kernels do not overlap, with per-stage HIP events recorded on the
-    launch stream (each blend / per-Gaussian stage is exactly one kernel launch)."""
+def profiled_stages(wl, api, exact, steps, world, dev, args, views_in_flight):
+    """K steps on ONE stream (kernels do not overlap) with per-stage HIP events recorded on the launch stream inside the
+    library; `views_in_flight` is passed to the library as the hint the multi-stream legs give it (it picks the kernel SHAPE
+    of the blend backward: render_bwd.hip blend_shape), so that the kernel timed here is the one the headline launched."""
     from luciddreamer_amd import _lib
     step = wl.make_step(api, exact, 1, not args.no_fused_accumulate)
-    step()
-    _lib.profile_enable(True)
-    dt_prof, _ = timed(step, steps, world, dev)
-    stages = _lib.profile_read()
-    _lib.profile_enable(False)
-    wl.finish()
+    _lib.tune_set("views_in_flight", views_in_flight if views_in_flight >= 2 else -1)
+    try:
+        step()
+        _lib.profile_enable(True)
+        dt_prof, _ = timed(step, steps, world, dev)
+        stages = _lib.profile_read()
+        _lib.profile_enable(False)
+        wl.finish()
+    finally:
+        _lib.tune_set("views_in_flight", -1)
+    return stages, dt_prof
+
+
+def roofline_leg(wl, api, exact, steps, world, dev, value, args):
+    """The same steps again on ONE stream so that kernels do not overlap, with per-stage HIP events recorded on the
+    launch stream (each blend / per-Gaussian stage is exactly one kernel launch).  Twice when the headline ran with several
+    views in flight: once with the kernel shapes those legs launch (the quoted figures), once as a lone view gets them
+    (`lone_view_shape`)."""
+    from luciddreamer_amd import _lib
+    in_flight = args.streams if api in ("views", "views-loss", "autograd") else 1
+    stages, dt_prof = profiled_stages(wl, api, exact, steps, world, dev, args, in_flight)
+    lone = None
+    if in_flight >= 2:
+        lone = profiled_stages(wl, api, exact, steps, world, dev, args, 1)[0]
+    # name of the blend-backward kernel each of the two passes launched (the rule of render_bwd.hip blend_shape)
+    bwd_tile = wl.T > 3072 and in_flight >= 2
+    bwd_name = "k_render_bwd_tile" if bwd_tile else "k_render_bwd<"
     P, V_mean, R_mean, N, T, K, M, V = wl.P, wl.V_mean, wl.R_mean, wl.N, wl.T, wl.K, wl.M, wl.V
     single_kernel = ("preprocess", "render_fwd", "render_bwd", "gauss_bwd")
     dom = max(single_kernel, key=lambda s: stages[s][0])
@@ -372,7 +398,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     # counters: VALU instructions, clocks) supplies `valu_issue`, and the bytes as well where no live pass ran (N > 1, other
     # workloads, --no-extras, a run that is itself being profiled); `traffic_source` says which.
     traffic, valu, source, traffic_ratios = None, None, None, None
-    traffic_file, source_file, live, live_note = None, None, None, None
+    traffic_file, source_file, live, live_note, dom_kernel = None, None, None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_c3.json")
     default_c3 = wl.name == "c3" and args.gaussians is None and args.views is None and args.resolution is None
     if default_c3 and world == 1 and not args.no_extras and not args.no_live_pmc and api == "views" and not exact:
@@ -390,7 +416,8 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
                 allpmc = {}
             # the kernel of the single-stream stage timing: the 2-wave k_render_bwd<...>, not the TILE shape the multi-stream legs
             # of the same run launch (k_render_bwd_tile) -- '<' sorts before '_'
-            pmc = pick_kernel(allpmc, dom)
+            prefer = bwd_name if dom == "render_bwd" else None
+            dom_kernel, pmc = pick_kernel(allpmc, dom, prefer)
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = int((2.0 * pmc["FETCH_SIZE"] + pmc["WRITE_SIZE"]) * 1024)
                 source = "committed PMC pass profiles/pmc_c3.json" + (f" ({allpmc['_collected']})" if "_collected" in allpmc else "")
@@ -402,7 +429,8 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
                     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                         allpmc.setdefault(k, {})
                         allpmc[k] = dict(allpmc[k], FETCH_SIZE=v["FETCH_SIZE"], WRITE_SIZE=v["WRITE_SIZE"])
-                lp = pick_kernel(live[0], dom)
+                lk, lp = pick_kernel(live[0], dom, prefer)
+                dom_kernel = lk or dom_kernel
                 if "FETCH_SIZE" in lp and "WRITE_SIZE" in lp:
                     traffic_file, traffic = traffic, int((2.0 * lp["FETCH_SIZE"] + lp["WRITE_SIZE"]) * 1024)
                     source_file, source = source, "live: " + live[1]
@@ -444,8 +472,27 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
         except (OSError, ValueError):
             traffic = None
     moved_view_s = b_moved / max(sum(stages[k][0] for k in stages) / max(V * steps, 1) * 1e-3, 1e-12)
+    lone_shape = None
+    if lone is not None:
+        ms, calls = lone[dom]
+        avg = ms / max(calls, 1) * 1e-3
+        lone_shape = {"kernel": "k_render_bwd<...> (2 waves per tile)" if dom == "render_bwd" and wl.T > 3072 else "k_" + dom,
+                      "avg_launch_ms": round(avg * 1e3, 4), "achieved": round(dom_bytes / avg / 1e9, 2),
+                      "frac": round(dom_bytes / avg / 1e9 / HBM_PEAK_GBS, 5),
+                      "what": "the same stage as a lone view gets it (views_in_flight = 1)"}
+    # every single-kernel stage of the path against the HBM peak (algorithmic bytes / its own launch time)
+    per_stage = {}
+    for st in single_kernel:
+        ms, calls = stages[st]
+        if calls:
+            ab = stage_bytes(st, P, V_mean, R_mean, N, T, K, M)
+            per_stage[st] = {"us": round(ms / calls * 1e3, 2), "algorithmic_bytes": int(ab),
+                             "frac": round(ab / (ms / calls * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
     return {
-        "bound": "hbm", "kernel": "k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "bound": "hbm", "kernel": dom_kernel or (bwd_name.rstrip("<") if dom == "render_bwd" else "k_" + dom),
+        "kernel_is_what_the_headline_launched": True, "views_in_flight_hint": in_flight,
+        "lone_view_shape": lone_shape, "per_stage": per_stage,
+        "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,
         "traffic_committed_file": traffic_file, "traffic_committed_file_source": source_file,
         "live_pmc": live_note, "valu_issue": valu,
@@ -713,16 +760,25 @@ def main():
         other = {}
         del wl
         torch.cuda.empty_cache()
-        for name in ("c2", "c3box", "c4shape"):
+        for name in ("c2", "c3box", "c4shape", "c5shape"):
             w2 = Workload(name, args, rank, world, dev)
             steps2 = max(2, min(args.steps, 5)) * (4 if name == "c2" else 1)
             v, ms, host, _ = run_leg(w2, "views", False, args.streams, steps2, 1, world, dev, fused)
+            # the stages of one view alone on the GPU (single stream, the shapes the multi-stream leg launches)
+            st2, _ = profiled_stages(w2, "views", False, 2, world, dev, args, args.streams)
+            per_stage = {}
+            for stg in ("preprocess", "render_fwd", "render_bwd", "gauss_bwd"):
+                if st2[stg][1]:
+                    ab = stage_bytes(stg, w2.P, w2.V_mean, w2.R_mean, w2.N, w2.T, w2.K, w2.M)
+                    us = st2[stg][0] / st2[stg][1] * 1e3
+                    per_stage[stg] = {"us": round(us, 1), "frac": round(ab / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)}
             b_f, b_b = path_bytes(w2.P, w2.V_mean, w2.R_mean, w2.N, w2.T, w2.K, w2.M)
             b_m = moved_bytes(w2.P, w2.V_mean, w2.R_mean, w2.N, w2.T, w2.K, w2.M, w2.V)
             other[name] = {"workload": w2.label, "value": round(v, 1), "unit": "views/s", "steps": steps2,
                            "ms_per_step": round(ms, 3), "visible_mean": round(w2.V_mean, 1),
                            "num_rendered_mean": round(w2.R_mean, 1),
-                           "path_frac_moved": round(b_m * v / (HBM_PEAK_GBS * 1e9), 5)}
+                           "path_frac_moved": round(b_m * v / (HBM_PEAK_GBS * 1e9), 5),
+                           "single_view_stage_us_and_frac_of_hbm_peak": per_stage}
             del w2
             torch.cuda.empty_cache()
 
@@ -750,6 +806,10 @@ def main():
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            # the same step with the blend evaluated in the reference's own float operations (config.set_strict_parity): the
+            # figure that meets the stated tolerance on EVERY pixel and gradient row with nothing masked (parity.strict_mode)
+            "strict_mode_views_per_s": (entry_points or {}).get("strict_mode_views_per_s"),
+            "strict_mode_parity": (parity or {}).get("strict_mode") if isinstance(parity, dict) else None,
             "config": cfg,
             "roofline": roofline,
             "parity": parity,

@@ -283,13 +283,29 @@ __device__ __forceinline__ float gauss_power_strict(float ca, float cb, float cc
 #pragma clang fp contract(off)
     return -0.5f * (ca * dx * dx + cc * dy * dy) - cb * dx * dy;
 }
+// expf as the device library evaluates it (ocml: x log2(e) as a compensated product, split into integer and fraction,
+// v_exp_f32 of the fraction, ldexp: <= 1 ulp), operation for operation -- without its two range checks (x < -104 -> 0,
+// x > 88.7 -> inf: a compare and a select each).  The same bits wherever the result is a normal number; beyond, v_ldexp_f32
+// under- and overflows to the same 0 / inf up to denormals, and an alpha that small is below 1/255 either way.  The strict-mode
+// tests (tests/test_gpu_ref_selfcal.py, test_gpu_variants.py: no pixel beyond 1e-5, no gradient row beyond 1e-4, nothing masked)
+// hold unchanged.
+__device__ __forceinline__ float strict_expf(float x)
+{
+#pragma clang fp contract(off)
+    const float c = 0x1.715476p+0f, cc = 0x1.4ae0bep-26f;       // log2(e) = c + cc
+    const float ph = x * c;
+    const float pl = __builtin_fmaf(x, cc, __builtin_fmaf(x, c, -ph));
+    const float e = __builtin_rintf(ph);
+    const float a = (ph - e) + pl;
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(a), (int)e);
+}
 // returns G = exp(power) and the value whose sign decides `power > 0` (log2(e) x power in the default mode)
 template <bool STRICT>
 __device__ __forceinline__ float gauss_weight(float qA, float qB, float qC, float r0, float r1, float dx, float& power)
 {
     if (STRICT) {
         power = gauss_power_strict(qA, qB, qC, dx, r0);
-        return expf(power);
+        return strict_expf(power);
     }
     power = gauss_power1(qA, r0, r1, dx);
     return __builtin_amdgcn_exp2f(power);
@@ -368,7 +384,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
 // are measured alternately in ONE process on ONE box (tools/ab_bench.py).  -1 = not set (the launcher's own rule).
-enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_PART_SCAN, TUNE_BWD_SEG, TUNE_COUNT };
+enum TuneKey { TUNE_BWD_RED = 0, TUNE_BLEND_QUAD, TUNE_TILE_MAP, TUNE_PREPROCESS, TUNE_GAUSS_BWD, TUNE_TSORT, TUNE_WALK_OWN, TUNE_HIT_MASK, TUNE_VIEWS_IN_FLIGHT, TUNE_STRICT, TUNE_PART_SCAN, TUNE_BWD_SEG, TUNE_FWD_PAIR, TUNE_COUNT };
 int tune_get(int key);
 
 // Shape of the backward blend kernel (render_bwd.hip, where the rule and its measurements are): BLEND_QUAD = 4 waves per

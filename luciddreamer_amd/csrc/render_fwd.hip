@@ -70,7 +70,29 @@ __device__ __forceinline__ void fwd_pixel(PixState& p, uint64_t& done, const flo
     }
 }
 
-template <bool STRICT>
+// The same step with the candidate's alpha already formed, and branch-free: for the PAIR loop below, where two candidates'
+// alphas are evaluated side by side and only these few dependent instructions per candidate remain in sequence.  `enable`:
+// all ones, or zero for the second half of an odd pair (the step is then the identity).
+__device__ __forceinline__ void fwd_step(PixState& p, uint64_t& done, const float alpha, const float power, const uint64_t enable,
+                                         const float cr, const float cg, const float cb, const float depth, const uint32_t pos0)
+{
+    const float test_T = p.T * (1.0f - alpha);
+    const uint64_t pass = enable & ~done & __builtin_amdgcn_ballot_w64(power <= 0.0f) & __builtin_amdgcn_ballot_w64(alpha >= 1.0f / 255.0f);
+    const uint64_t low_T = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+    const uint64_t stop = pass & low_T;
+    const bool use = __builtin_amdgcn_inverse_ballot_w64(pass & ~low_T);
+    done |= stop;
+    const float wgt = use ? alpha * p.T : 0.f;
+    p.Cr += cr * wgt; p.Cg += cg * wgt; p.Cb += cb * wgt; p.D += depth * wgt; p.acc += wgt;
+    p.T = use ? test_T : p.T;
+    p.last = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos0 : p.last;
+}
+
+// PAIR: the candidate loop takes two candidates per round (small images: few waves per SIMD, the kernel time is the longest
+// wave's dependent chain -- LDS read, exponent, v_exp, the T recursion -- and two candidates' chains overlap except for the
+// recursion itself; profiles/r05a_pmc_c5shape.json: VALU busy 49 %, 2.2 waves resident per SIMD on average at 512^2).
+// Same operations per pixel and candidate in the same order: bit-identical images.
+template <bool STRICT, bool PAIR>
 __global__ void __launch_bounds__(THREADS)
 k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
@@ -161,6 +183,31 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             uint64_t mask = __ballot(hit);
             // BLEND: walk the candidates in list order (a non-candidate is exactly the reference's `continue`: no pixel of
             // the quadrant can reach alpha >= 1/255)
+            if constexpr (PAIR) {
+                while (mask) {
+                    const int k0 = __ffsll((long long)mask) - 1;
+                    mask &= mask - 1;
+                    const bool two = mask != 0ull;
+                    const int k1 = two ? __ffsll((long long)mask) - 1 : k0;
+                    mask &= mask - 1;                                                  // (0 & anything = 0)
+                    const int j0 = sb + k0, j1 = sb + k1;
+                    float4 a0 = s_q0[j0], a1 = s_q0[j1];
+                    float4 b0 = s_q1[j0], b1 = s_q1[j1];
+                    const float4 c0 = s_q2[j0], c1 = s_q2[j1];
+                    // Both candidates' reads are in flight before any arithmetic, and both alphas exist before the first step of
+                    // the recursion: the empty asm statements tie the two candidates' values together (left to itself the compiler
+                    // finishes candidate 0 -- reads, exponent, step -- before it even issues the reads of candidate 1)
+                    asm volatile("" : "+v"(a0.x), "+v"(a0.y), "+v"(a0.z), "+v"(a0.w), "+v"(b0.x), "+v"(a1.x), "+v"(a1.y), "+v"(a1.z), "+v"(a1.w), "+v"(b1.x));
+                    float r00, r01, r10, r11, power0, power1;
+                    gauss_row<STRICT>(a0.w, b0.x, a0.y - pyf, r00, r01);                        // common.h gauss_power
+                    gauss_row<STRICT>(a1.w, b1.x, a1.y - pyf, r10, r11);
+                    float alpha0 = fminf(0.99f, b0.y * gauss_weight<STRICT>(a0.z, a0.w, b0.x, r00, r01, a0.x - pxf, power0));
+                    float alpha1 = fminf(0.99f, b1.y * gauss_weight<STRICT>(a1.z, a1.w, b1.x, r10, r11, a1.x - pxf, power1));
+                    asm volatile("" : "+v"(alpha0), "+v"(alpha1), "+v"(power0), "+v"(power1));
+                    fwd_step(A, done, alpha0, power0, ~0ull, c0.x, c0.y, c0.z, b0.z, (uint32_t)(base + j0));
+                    fwd_step(A, done, alpha1, power1, two ? ~0ull : 0ull, c1.x, c1.y, c1.z, b1.z, (uint32_t)(base + j1));
+                }
+            } else
             while (mask) {
                 const int k = __ffsll((long long)mask) - 1;
                 mask &= mask - 1;
@@ -210,12 +257,15 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    if (tune_get(TUNE_STRICT) > 0)
-        hipLaunchKernelGGL(k_render_fwd<true>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
-                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0);
-    else
-        hipLaunchKernelGGL(k_render_fwd<false>, dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, point_list,
-                           inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0);
+    // lr_tune_set("fwd_pair", 0 / 1) forces the candidate loop (A/B runs); default: pairs where the image has few tiles
+    const bool pair = tune_get(TUNE_FWD_PAIR) >= 0 ? tune_get(TUNE_FWD_PAIR) != 0 : num_tiles <= 3072;
+    const bool strict = tune_get(TUNE_STRICT) > 0;
+#define LR_FWD(S, PR) hipLaunchKernelGGL((k_render_fwd<S, PR>), dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, \
+                                         point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr,   \
+                                         seg_list, ckpt, tile_seg0)
+    if (strict) { if (pair) LR_FWD(true, true); else LR_FWD(true, false); }
+    else { if (pair) LR_FWD(false, true); else LR_FWD(false, false); }
+#undef LR_FWD
 }
 
 }  // namespace lr

@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan", "bwd_seg"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan", "bwd_seg", "fwd_pair"):
         _lib.tune_set(k, -1)
 
 
@@ -331,3 +331,24 @@ def test_list_segments_give_the_gradients_of_the_whole_list(hip_device, shape, P
         assert np.array_equal(segs["grads"][k], again["grads"][k]), k
     assert all(float(np.abs(whole["grads"][k]).max()) > 0 for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
     hp.compare_grads_by_row(segs, ref, P)
+
+
+@pytest.mark.parametrize("P,W,H,scale_mult", [(60_000, 640, 360, 1.0), (40_000, 320, 208, 5.0), (20_000, 1280, 720, 2.0)])
+def test_forward_candidate_pairs_give_the_same_bits(hip_device, P, W, H, scale_mult):
+    """Small images take the blend forward's candidates two at a time (render_fwd.hip PAIR: both alphas side by side, then the
+    two steps of the T recursion in order); lr_tune_set("fwd_pair", 0 / 1) forces either loop.  Same operations per pixel and
+    candidate in the same order: images, depth, n_contrib (through the gradients) and checkpoints are the same bits."""
+    cam, cloud = hp.box_setup(P, W, H, seed=21, scale_mult=scale_mult)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.3, 0.1, 0.2])
+    outs = []
+    try:
+        for v in (0, 1):
+            _lib.tune_set("fwd_pair", v)
+            outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
+    finally:
+        _lib.tune_set("fwd_pair", -1)
+    a, b = outs
+    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
+    for k in a["grads"]:
+        assert np.array_equal(a["grads"][k], b["grads"][k]), k
