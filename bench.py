@@ -187,6 +187,24 @@ class Workload:
                     batch.run(self.m2d_grad, reduce=False)
                     opt.step()
                 return step
+            if api == "views" and getattr(self.args, "exchange", "allreduce") == "split-sharded-adam":
+                # the same training step with the parameter all-gather split (parallel.SplitShardedAdam): geometry (44 B per
+                # Gaussian) joined inside the optimizer step, the SH gather (192 B) left in flight until the next step's first
+                # forward needs it -- here: until the bucket is zeroed and the views are issued again
+                ordered = {k: torch.nn.Parameter(named[k].detach()) for k in parallel.ChunkedViewStep.ORDER}
+                lrs = dict(zip(parallel.ChunkedViewStep.ORDER, [1.6e-4, 5e-3, 1e-3, 5e-2, 2.5e-3]))
+                self.opt = parallel.SplitShardedAdam(ordered, lrs)
+                self.batch = parallel.ChunkedViewStep(self.cams, [self.grad_color] * len(self.cams), ordered, self.degree,
+                                                      self.bg, self.capacity, n_streams=streams, chunks=1, grads=self.opt.grads)
+                self.exchange_phases = self.opt.bytes_per_step
+                batch, opt = self.batch, self.opt
+
+                def step():
+                    self.m2d_grad.zero_()          # (everything that reads geometry only could be issued here, before the join)
+                    opt.wait()                     # the SH rows of the last step's gather: the forward reads them
+                    batch.run(self.m2d_grad, reduce=False)
+                    opt.step()
+                return step
             if api == "views" and getattr(self.args, "exchange", "allreduce") == "sparse-rows":
                 # the same sum as the all-reduce; only the rows this rank's views touched travel in the reduce half
                 self.chunks = 1
@@ -651,7 +669,7 @@ def main():
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
                     help="N > 1: strong = the workload's views per STEP shared by the ranks (BASELINE.json config 3; auto picks it), "
                          "weak = that many views per rank")
-    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sparse-rows", "sharded-adam"],
+    ap.add_argument("--exchange", default="allreduce", choices=["allreduce", "sparse-rows", "sharded-adam", "split-sharded-adam"],
                     help="views API: allreduce = the metric's step (gradients all-reduced, one dense bucket); sparse-rows = the same "
                          "sum with the reduce-scatter half replaced by an all-to-all of the rows this rank's views touched "
                          "(parallel.sparse_rows_all_reduce); sharded-adam = a training step, reduce-scatter + Adam on the rank's "
@@ -796,7 +814,7 @@ def main():
                     "allreduce_bytes_per_step": (exchange_bytes if exchange_bytes is not None else
                                                  int(2 * (world - 1) * bucket_bytes * chunks // world)) if world > 1 else 0,
                     "allreduce_payload_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
-                    "exchange_detail": exchange_detail,
+                    "exchange_detail": exchange_detail if exchange_detail is not None else getattr(wl, "exchange_phases", None),
                     "dist_backend": backend, "dist_world_size": backend_world, "collective_check": collective_check,
                     "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),

@@ -276,9 +276,10 @@ class ShardedAdam:
             shard.copy_(mine[self.lo:self.hi])
 
     @torch.no_grad()
-    def step(self):
+    def step(self, async_gather: bool = False):
         """Gradients of this rank's views are in self.grads.flat (accumulated); afterwards every rank holds the updated
-        parameters.  The bucket is left as it was (zero it before the next step: FlatGrads.zero_)."""
+        parameters.  The bucket is left as it was (zero it before the next step: FlatGrads.zero_).  async_gather: return the
+        handle of the parameter all-gather instead of joining it (None on one rank)."""
         self.step_count += 1
         flat_g, flat_p = self.grads.flat, self.params.flat
         if self.world > 1:
@@ -291,7 +292,89 @@ class ShardedAdam:
                   for o, n, t in self.pieces]
         self.adam_fn(pieces, self.betas[0], self.betas[1], self.eps, self.step_count)
         if self.world > 1:
-            dist.all_gather_into_tensor(flat_p, p_shard)      # in place: rank r's input IS slice r of the output
+            # in place: rank r's input IS slice r of the output.  async_gather: the collective is left in flight and its
+            # handle returned -- the caller decides what may run before the parameters of THIS bucket are needed again
+            if async_gather:
+                return dist.all_gather_into_tensor(flat_p, p_shard, async_op=True)
+            dist.all_gather_into_tensor(flat_p, p_shard)
+        return None
+
+
+class SplitShardedAdam:
+    """ShardedAdam over TWO buckets so that the parameter all-gather comes back in the order the next step needs it:
+
+        geometry   means3D, scales, rotations, opacity   11 floats =  44 B per Gaussian   (19 % of the exchange)
+        appearance sh                                    48 floats = 192 B per Gaussian   (81 %)
+
+    Each bucket is sharded by flat index over all ranks and stepped like ShardedAdam (reduce-scatter, Adam on the shard,
+    all-gather); Adam is element-wise, so the parameters after a step are bit for bit those of one ShardedAdam over all five
+    tensors, whatever the shard boundaries (tests/test_parallel_gloo.py).  step() returns once the GEOMETRY parameters are
+    complete on every rank; the appearance all-gather is still in flight (RCCL runs it on its own stream) and `wait()` joins
+    it.  Everything that reads only geometry may be issued in between -- frustum culling / mark_visible of the next step's
+    views (R/gaussian_renderer: `visibility_filter`), the densification statistics and their reduction, densify_and_prune's
+    masks -- and the next step's first preprocess has to follow `wait()` only because the fused kernel also evaluates the SH
+    colour of the survivors (preprocess.hip).  `bytes_per_step` gives what a rank puts on its links per phase (ring model)."""
+
+    GEOMETRY = ("means3D", "scales", "rotations", "opacity")
+
+    def __init__(self, named_params, lrs, betas=(0.9, 0.999), eps: float = 1e-15, adam_fn: Optional[Callable] = None):
+        """named_params: {"means3D", "scales", "rotations", "opacity", "sh"} -> parameter tensors; lrs: {name: learning rate}."""
+        order = list(self.GEOMETRY) + ["sh"]
+        self.named = {k: named_params[k] for k in order}
+        geo = [self.named[k] for k in self.GEOMETRY]
+        self.grads_geometry = ShardedAdam.make_buckets(geo)
+        self.grads_appearance = ShardedAdam.make_buckets([self.named["sh"]])
+        self.geometry = ShardedAdam(geo, self.grads_geometry, [lrs[k] for k in self.GEOMETRY], betas, eps, adam_fn)
+        self.appearance = ShardedAdam([self.named["sh"]], self.grads_appearance, [lrs["sh"]], betas, eps, adam_fn)
+        self._pending = None
+
+    def zero_grad(self):
+        self.grads_geometry.zero_()
+        self.grads_appearance.zero_()
+
+    class _Buckets:
+        """The two buckets behind the interface ChunkedViewStep uses of one FlatGrads (views in ORDER, zero_); there is no
+        single flat buffer: the exchange is this optimizer's (ChunkedViewStep.run(reduce=False))."""
+
+        def __init__(self, geometry: FlatGrads, appearance: FlatGrads):
+            self.parts = (geometry, appearance)
+            self.views = list(geometry.views) + list(appearance.views)
+            self.segments = None
+            self.flat = None
+
+        def zero_(self):
+            for b in self.parts:
+                b.zero_()
+
+    @property
+    def grads(self):
+        return SplitShardedAdam._Buckets(self.grads_geometry, self.grads_appearance)
+
+    @torch.no_grad()
+    def step(self):
+        """Both buckets: reduce-scatter + Adam on the shard; all-gather of the geometry (joined here), all-gather of the
+        appearance left in flight (joined by wait(), or by the next step())."""
+        self.wait()
+        # the big bucket first: its reduce-scatter and Adam are issued before the small bucket's collectives, and its
+        # all-gather is the one left running
+        self._pending = self.appearance.step(async_gather=True)
+        self.geometry.step()
+        return self._pending
+
+    def wait(self):
+        """Join the appearance all-gather of the last step (no-op when none is in flight)."""
+        if self._pending is not None:
+            self._pending.wait()
+            self._pending = None
+
+    @property
+    def bytes_per_step(self):
+        n = world_size()
+        g, a = self.grads_geometry.flat.numel() * 4, self.grads_appearance.flat.numel() * 4
+        half = lambda b: int((n - 1) * b // n)                 # one reduce-scatter or one all-gather of b bytes (ring)
+        return {"reduce_scatter": half(g) + half(a), "all_gather_geometry_joined_in_step": half(g),
+                "all_gather_appearance_left_in_flight": half(a),
+                "overlap_window": "from the return of step() to wait(): the appearance all-gather (81 % of the gather half)"}
 
 
 REDUCE_CHUNKS = 1

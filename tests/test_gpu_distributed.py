@@ -145,3 +145,17 @@ def test_bench_refuses_a_world_size_that_is_not_gpus(hip_device):
     r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "1", "--gaussians", "100000",
                       "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extras"], 29629)
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+
+
+def test_bench_split_sharded_adam_reports_the_overlap_window(hip_device):
+    """--exchange split-sharded-adam: the training step with the parameter all-gather in two parts (parallel.SplitShardedAdam);
+    the line says how many bytes are joined inside the optimizer step (geometry) and how many are left in flight (SH)."""
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "100000",
+                      "--views", "4", "--resolution", "640x360", "--no-cpu-baseline", "--sustain-seconds", "0", "--no-extras",
+                      "--exchange", "split-sharded-adam"], 29631)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    cfg = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])["config"]
+    d = cfg["exchange_detail"]
+    assert cfg["exchange"] == "split-sharded-adam" and cfg["collective_check"]["all_reduce_of_ones"] == 2.0
+    assert 0 < d["all_gather_geometry_joined_in_step"] < d["all_gather_appearance_left_in_flight"]
+    assert d["reduce_scatter"] == d["all_gather_geometry_joined_in_step"] + d["all_gather_appearance_left_in_flight"]

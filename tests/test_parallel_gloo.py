@@ -179,6 +179,58 @@ def test_sharded_adam_two_ranks_equal_unsharded(tmp_path):
         assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(b).max()), float(np.abs(a - b).max())
 
 
+def _split_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed(backend="gloo", device=torch.device("cpu"))
+    cloud, _ = _make_problem()
+    keys = ("means3D", "scales", "rotations", "opacities", "shs")
+    names = ("means3D", "scales", "rotations", "opacity", "sh")
+    named = {n: torch.nn.Parameter(cloud[k].clone()) for n, k in zip(names, keys)}
+    twin = [torch.nn.Parameter(cloud[k].clone()) for k in keys]                          # the unsplit step, same ranks
+    grads1 = parallel.ShardedAdam.make_buckets(twin)
+    one = parallel.ShardedAdam(twin, grads1, LRS, adam_fn=_torch_adam_pieces)
+    split = parallel.SplitShardedAdam(named, dict(zip(names, LRS)), adam_fn=_torch_adam_pieces)
+    params = [named[n] for n in names]
+    geometry_ready = []
+    for it in range(3):
+        split.zero_grad()
+        grads1.zero_()
+        for p, q, g in zip(params, twin, _fake_view_grads(params, rank, world, 7, it)):
+            p.grad.add_(g)
+            q.grad.add_(g)
+        handle = split.step()
+        # step() has joined the geometry gather: those parameters are final on every rank while the SH gather may still run
+        geometry_ready.append([p.detach().clone() for p in params[:4]])
+        assert (handle is None) == (world == 1)
+        split.wait()
+        one.step()
+        for before, p in zip(geometry_ready[-1], params[:4]):
+            assert torch.equal(before, p.detach())
+    bytes_ = split.bytes_per_step
+    np.savez(os.path.join(out_dir, f"sp{rank}.npz"), **{f"s{i}": p.detach().numpy() for i, p in enumerate(params)},
+             **{f"o{i}": q.detach().numpy() for i, q in enumerate(twin)},
+             geo=bytes_["all_gather_geometry_joined_in_step"], app=bytes_["all_gather_appearance_left_in_flight"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_split_sharded_adam_equals_the_unsplit_step_and_returns_geometry_first(tmp_path):
+    """the parameter all-gather in the order the next step needs it.  SplitShardedAdam steps a geometry
+    bucket (44 B per Gaussian) and an appearance bucket (192 B) -- its step() returns with the geometry complete on every rank
+    and the SH gather still in flight -- and must leave the parameters of ONE ShardedAdam over all five tensors, bit for bit
+    (Adam is element-wise: the shard boundaries do not matter), on both ranks."""
+    world = 2
+    mp.spawn(_split_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = np.load(tmp_path / "sp0.npz"), np.load(tmp_path / "sp1.npz")
+    for i in range(5):
+        assert np.array_equal(r0[f"s{i}"], r1[f"s{i}"]), "replicas diverged"
+        assert np.array_equal(r0[f"s{i}"], r0[f"o{i}"]), f"tensor {i}: split step differs from the unsplit one"
+    # 11 of 59 floats per Gaussian are joined inside step(); the other 48 are the window
+    assert 0.17 < float(r0["geo"]) / float(r0["geo"] + r0["app"]) < 0.21
+
+
 def test_sharded_adam_single_rank_is_plain_adam():
     cloud, _ = _make_problem()
     params = [torch.nn.Parameter(cloud[k].clone()) for k in ("means3D", "scales", "rotations", "opacities", "shs")]

@@ -12,7 +12,8 @@
 #include <vector>
 #include <algorithm>
 
-constexpr int ITER = 2048;
+constexpr int ITER = 32768;      // ~0.6 ms per wave: every workgroup of a launch is resident at once (a short kernel's
+                                 // later workgroups start after its first ones ended: fewer waves share a SIMD than launched)
 
 #define OP8(STR) asm volatile(STR(0) STR(1) STR(2) STR(3) STR(4) STR(5) STR(6) STR(7) \
     : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]) : "v"(m), "v"(c) : "vcc", "s20", "s21")
@@ -97,7 +98,9 @@ void run(const char* name, unsigned long long* dticks, float* dsink)
         std::sort(t.begin(), t.end());
         const double med = (double)t[t.size() / 2], n = (double)ITER * 8;
         // s_memtime on gfx950 counts at a fixed 100 MHz reference, or shader cycles: print both readings of it
-        printf(" | W=%d %6.2f tick/instr/SIMD (med %8.0f ticks, launch %.3f ms => %.2f Gtick/s)", W, med / (n * W), med, ms, med / (ms * 1e6));
+        // resident together? then the launch lasts about as long as one wave (ticks / launch time = the shader clock, ~2 GHz)
+        printf(" | W=%d %5.2f cyc/instr/SIMD (%5.2f per wave; wave %4.0f us of a %4.0f us launch at 2.1 GHz)", W, med / (n * W), med / n,
+               med / 2.1e3, ms * 1e3);
     }
     printf("\n");
 }
