@@ -400,6 +400,9 @@ long long lr_forward_ticket(void);
  * tensors must be anyway; `stream` of lr_step_end must be ordered after all of them.  Returns 0 or a negative LR_ERR_*. */
 int lr_step_begin(void);
 int lr_step_end(void* stream);
+/* Close a step WITHOUT handing its rows over: for a step that was abandoned (error in the caller's loop, a begin whose end never
+ * came).  The tensors named by its views may be gone by then; nothing is written through the remembered pointers. */
+int lr_step_abort(void);
 /* Accumulate-mode backward passes of different views on different streams add into the SAME gradient tensors and must not
  * overlap there.  `event` (a hipEvent_t, or NULL) is consumed by the next lr_backward / lr_backward_raw on the calling thread:
  * its stream waits for the event after the blend backward (which writes only the call's own scratch) and before the kernels

@@ -27,7 +27,7 @@ _lock = threading.Lock()
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
            "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
            "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read", "lr_tune_set", "lr_request_early_header",
-           "lr_take_early_ticket", "lr_forward_ticket", "lr_backward_wait_event", "lr_step_begin", "lr_step_end",
+           "lr_take_early_ticket", "lr_forward_ticket", "lr_backward_wait_event", "lr_step_begin", "lr_step_end", "lr_step_abort",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward", "lr_l1_dssim_backward_weights",
            "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats",
@@ -137,6 +137,8 @@ def lib():
         L.lr_step_begin.argtypes = []
         L.lr_step_end.restype = ci
         L.lr_step_end.argtypes = [vp]
+        L.lr_step_abort.restype = ci
+        L.lr_step_abort.argtypes = []
         L.lr_forward_ticket.restype = ctypes.c_longlong
         L.lr_forward_ticket.argtypes = []
         L.lr_tune_set.restype = ci

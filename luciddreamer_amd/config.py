@@ -49,6 +49,7 @@ rerendered_views = 0 # views rendered again in exact mode by the "verify" policy
 recovered_views = 0  # views of a ViewStreams step that overflowed and were run again in exact mode at end_step()
 
 POLICIES = ("verify", "drop", "raise", "recover")
+PUBLIC_POLICIES = ("verify", "drop", "raise")      # "recover" belongs to parallel.ViewStreams (overflow_policy(..., _owner=...))
 
 
 def _stack():
@@ -67,8 +68,10 @@ def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 1, warm_c
     call; k > 1 samples (views in between can overflow unnoticed -- their gradients are still zero, never wrong -- and do
     not feed the mark)."""
     global _async, _headroom, _CHECK_EVERY, _warm_calls, _on_overflow
-    if on_overflow not in POLICIES:
-        raise ValueError(f"on_overflow must be one of {POLICIES}")
+    if on_overflow not in PUBLIC_POLICIES:
+        # "recover" needs an owner that runs a lost view again (parallel.ViewStreams); as a global policy an overflowed view
+        # would silently contribute nothing
+        raise ValueError(f"on_overflow must be one of {PUBLIC_POLICIES}")
     _async = bool(enabled)
     _headroom = float(headroom)
     _CHECK_EVERY = max(1, int(check_every))
@@ -81,9 +84,10 @@ def set_async(enabled: bool, headroom: float = 1.3, check_every: int = 1, warm_c
 class overflow_policy:
     """Context manager: a temporary policy (parallel.ViewStreams keeps views in flight and must not wait in backward)."""
 
-    def __init__(self, policy):
-        if policy not in POLICIES:
-            raise ValueError(f"policy must be one of {POLICIES}")
+    def __init__(self, policy, _owner=None):
+        """_owner: the object that re-runs overflowed views -- required for "recover" (parallel.ViewStreams passes itself)."""
+        if policy not in POLICIES or (policy == "recover" and _owner is None):
+            raise ValueError(f"policy must be one of {PUBLIC_POLICIES}")
         self.policy = policy
 
     def __enter__(self):

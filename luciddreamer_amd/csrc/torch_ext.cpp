@@ -88,6 +88,15 @@ AccumulateChain& accumulate_chain(int device)
     }
     return c;
 }
+// Set by the compiled autograd node for the duration of a backward that runs under fused gradient accumulation: such a
+// backward joins the chain even when IT only writes (the first view of a step whose leaves have no .grad yet: its result
+// becomes the .grad the next view -- possibly on another stream -- accumulates into).
+thread_local bool t_fused_backward = false;
+struct FusedBackwardScope {
+    bool prev;
+    explicit FusedBackwardScope(bool on) : prev(t_fused_backward) { t_fused_backward = on; }
+    ~FusedBackwardScope() { t_fused_backward = prev; }
+};
 struct ChainScope {
     AccumulateChain* c = nullptr;
     hipStream_t s = nullptr;
@@ -214,7 +223,7 @@ std::vector<OptT> rasterize_gaussians_backward(
                   gc = f32(dL_dout_color, dev, "dL_dout_color"), gd = f32(dL_dout_depth, dev, "dL_dout_depth");
         const at::Tensor radii_c = radii.contiguous();
         hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-        ChainScope chain(mask != 0, dev.index(), cur);
+        ChainScope chain(mask != 0 || t_fused_backward, dev.index(), cur);
         const int rc = lr_backward(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
                                    static_cast<int>(H), m.p, shc.p, col.p, sc.p, static_cast<float>(scale_modifier), rot.p, cov.p,
                                    view.p, proj.p, cam.p, static_cast<float>(tan_fovx), static_cast<float>(tan_fovy),
@@ -416,6 +425,7 @@ struct RasterizeFn : public torch::autograd::Function<RasterizeFn> {
         if (fused)
             acc = { leaf_grad(means2D), leaf_grad(colors), leaf_grad(opacities), leaf_grad(means3D), leaf_grad(cov3D), leaf_grad(sh),
                     leaf_grad(scales), leaf_grad(rotations) };
+        FusedBackwardScope fused_scope(fused);
         const std::vector<OptT> g = rasterize_gaussians_backward(
             bg, means3D, d["radii"].toTensor(), colors, scales, rotations, d["scale_modifier"].toDouble(), cov3D, viewmatrix,
             projmatrix, d["tan_fovx"].toDouble(), d["tan_fovy"].toDouble(), g_color, g_depth, sh, d["degree"].toInt(), campos,

@@ -133,12 +133,17 @@ class PairedLoss:
                 and a.shape[-3] == 3 and a.dtype == torch.float32 and b.dtype == torch.float32)
 
     def _get(self, a, b):
-        key = (id(a), id(b), a._version, b._version, a.data_ptr(), b.data_ptr())
-        if self._key == key and self._pair is not None:
+        # the pending pair is keyed on the tensor OBJECTS (held here until the second call or the next key: an id() alone can
+        # be re-used by a later tensor at the same allocator address once the first is gone -- eval loops under no_grad) and
+        # their versions
+        k = self._key
+        if (k is not None and self._pair is not None and k[0] is a and k[1] is b and k[2] == a._version
+                and k[3] == b._version and k[4] == a.data_ptr() and k[5] == b.data_ptr()):
             pair, self._key, self._pair = self._pair, None, None       # second of the two calls: hand out and forget
             return pair
+        self._key, self._pair = None, None                             # another pair: drop the graph / workspace of the old one
         pair = _L1SSIMPair.apply(a, b)
-        self._key, self._pair = key, pair
+        self._key, self._pair = (a, b, a._version, b._version, a.data_ptr(), b.data_ptr()), pair
         return pair
 
     def l1_loss(self, network_output, gt):

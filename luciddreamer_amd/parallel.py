@@ -644,7 +644,7 @@ class ViewStreams:
         # several views in flight: a forward must not wait for its own header copy (config "verify" does).  "recover": every
         # view's header is examined at end_step() and a view that overflowed its binning buffer -- the device-side guard
         # zeroed its gradients -- is run again in exact mode there, so no view of the step is lost
-        self._policy = config.overflow_policy(self.on_overflow)
+        self._policy = config.overflow_policy(self.on_overflow, _owner=self)
         self._policy.__enter__()
         self._views = []
         self._deferred = []
@@ -655,22 +655,26 @@ class ViewStreams:
         # (lr_step_begin: what lr_views_accumulate does internally); end_step hands the rows to the .grad tensors
         L = _lib.lib()
         with torch.cuda.device(self.device):
-            if L.lr_step_begin() < 0:                        # a step that never reached end_step()
-                L.lr_step_end(cur.cuda_stream)
+            if L.lr_step_begin() < 0:                        # a step that never reached end_step(): its rows are dropped, not
+                L.lr_step_abort()                            # flushed (its target tensors may be gone: ADVICE r4)
                 L.lr_step_begin()
         self._step_open = True
 
-    def _close_step(self, stream):
+    def _close_step(self, stream, abort=False):
         from . import _lib
         if getattr(self, "_step_open", False):
             self._step_open = False
             with torch.cuda.device(self.device):
-                if _lib.lib().lr_step_end(stream.cuda_stream) < 0:
+                if abort:
+                    _lib.lib().lr_step_abort()
+                elif _lib.lib().lr_step_end(stream.cuda_stream) < 0:
                     _lib.raise_for(-1, "lr_step_end")
 
     def _pop_policy(self):
+        """Leaves the step's policy / tuning state; a step still open here did not reach end_step() (it closes the step itself
+        first): an exception in the caller's loop -- what it accumulated is dropped."""
         from . import _lib
-        self._close_step(torch.cuda.current_stream(self.device))
+        self._close_step(torch.cuda.current_stream(self.device), abort=True)
         if getattr(self, "_policy", None) is not None:
             self._policy.__exit__(None, None, None)
             self._policy = None

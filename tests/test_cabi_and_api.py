@@ -195,8 +195,8 @@ def test_division_free_index_arithmetic_of_the_binning_is_exact():
 
 def test_bench_reads_rocprofv3_counter_files_and_picks_the_timed_kernel(tmp_path):
     """bench.py's live byte-counter leg: the csv rocprofv3 --pmc writes (one row per dispatch and counter) averaged per kernel and
-    launch, and the record of the kernel the single-stream stage timing belongs to (the 2-wave k_render_bwd<...>, not the TILE
-    shape's k_render_bwd_tile that the multi-stream legs of the same run launch)."""
+    launch, and the record of the kernel a stage timing belongs to (the blend backward has several shapes: the roofline leg names
+    the one the headline launched)."""
     import bench
     d = tmp_path / "FETCH_SIZE" / "box"
     d.mkdir(parents=True)
@@ -212,6 +212,9 @@ def test_bench_reads_rocprofv3_counter_files_and_picks_the_timed_kernel(tmp_path
     assert bench.read_counter_csv(str(tmp_path / "FETCH_SIZE"), "FETCH_SIZE", acc) == 4          # the SQ_WAVES row is not this pass's
     assert acc["k_render_bwd<false, true, false>"]["FETCH_SIZE"] == [64000.0, 2] and acc["k_render_bwd_tile"]["FETCH_SIZE"] == [50000.0, 1]
     mean = {k: {c: v[0] / v[1] for c, v in cs.items()} for k, cs in acc.items()}
-    assert bench.pick_kernel(mean, "render_bwd") == {"FETCH_SIZE": 32000.0}
-    assert bench.pick_kernel(mean, "gauss_bwd") == {}
+    # the kernel a stage timing belongs to: the shape the timed leg launched when the caller names it (the multi-stream
+    # headline at 1080p launches k_render_bwd_tile), else k_<stage><...> first
+    assert bench.pick_kernel(mean, "render_bwd") == ("k_render_bwd<false, true, false>", {"FETCH_SIZE": 32000.0})
+    assert bench.pick_kernel(mean, "render_bwd", "k_render_bwd_tile") == ("k_render_bwd_tile", {"FETCH_SIZE": 50000.0})
+    assert bench.pick_kernel(mean, "gauss_bwd") == (None, {})
     assert bench.read_counter_csv(str(tmp_path / "nothing_here"), "FETCH_SIZE", {}) == 0

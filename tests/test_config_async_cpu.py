@@ -178,7 +178,7 @@ def test_recover_policy_marks_the_view_and_neither_warns_nor_counts_a_drop(fake)
     config.set_async(True, headroom=1.0, warm_calls=1, check_every=4)
     config.note_forward(means, rs, 1_000, None, 0)
     cap = config.capacity_for(means, rs)
-    with config.overflow_policy("recover"):
+    with config.overflow_policy("recover", _owner=object()):
         assert not config.verifying(cap)
         for h in (_header(900), _header(50_000, overflow=1), _header(950)):
             config.note_forward(means, rs, -1, h, cap)
@@ -204,7 +204,7 @@ def test_a_forward_is_tied_to_its_own_entry_even_when_it_retires_older_ones(fake
     means, rs = torch.zeros(500, 3), _rs()
     config.set_async(True, headroom=1.0, warm_calls=1)
     config.note_forward(means, rs, 1_000, None, 0)
-    with config.overflow_policy("recover"):
+    with config.overflow_policy("recover", _owner=object()):
         cap = config.capacity_for(means, rs)
         config.note_forward(means, rs, -1, _header(900), cap)
         first = config.take_last_entry()
@@ -237,3 +237,13 @@ def test_policy_stack_is_per_thread_and_tolerates_an_unbalanced_exit(fake):
     assert seen["other"] == "verify"                                 # another thread never sees this thread's override
     config.overflow_policy("drop").__exit__(None, None, None)        # exit without enter: no IndexError, nothing popped
     assert config.current_policy() == "verify"
+
+
+def test_recover_is_not_a_public_policy():
+    """"recover" only makes sense with an owner that runs an overflowed view again (parallel.ViewStreams); as a
+    global policy the view would silently contribute nothing."""
+    with pytest.raises(ValueError):
+        config.set_async(True, on_overflow="recover")
+    with pytest.raises(ValueError):
+        config.overflow_policy("recover")
+    config.overflow_policy("recover", _owner=object())
