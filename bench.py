@@ -713,6 +713,7 @@ def main():
     fused = not args.no_fused_accumulate
     value, ms_per_step, host_issue_ms, step_fn = run_leg(wl, args.api, args.exact, args.streams, args.steps, args.warmup, world, dev, fused)
     chunks = wl.chunks
+    exchange_phases = getattr(wl, "exchange_phases", None)
     exchange_bytes, exchange_detail = None, None
     info = getattr(wl, "exchange_info", None)
     if info:                                            # sparse-rows: measured per step (the last `steps` calls are the timed ones)
@@ -814,7 +815,7 @@ def main():
                     "allreduce_bytes_per_step": (exchange_bytes if exchange_bytes is not None else
                                                  int(2 * (world - 1) * bucket_bytes * chunks // world)) if world > 1 else 0,
                     "allreduce_payload_bytes_per_step": int(bucket_bytes * chunks) if world > 1 else 0,
-                    "exchange_detail": exchange_detail if exchange_detail is not None else getattr(wl, "exchange_phases", None),
+                    "exchange_detail": exchange_detail if exchange_detail is not None else exchange_phases,
                     "dist_backend": backend, "dist_world_size": backend_world, "collective_check": collective_check,
                     "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
@@ -957,7 +958,7 @@ def run_cpu_baseline(wl):
                 config.set_async(True, on_overflow=policy)
                 for _pass in range(2):
                     with ref_loop.stack("ours") as (R, dev):
-                        handle = luciddreamer_amd.install(R)
+                        handle = luciddreamer_amd.install(R, backward_on_calling_thread=True)    # the single-threaded loop: what "auto" picks there
                         try:
                             gm = ref_loop.model_from_cloud(R, base, dev)
                             cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)

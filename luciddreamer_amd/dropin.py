@@ -180,11 +180,12 @@ def _raw_ok(pc, opt, override_color):
 
 
 def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=True, losses=True, adam=True, stats=True,
-            densify=True, rebind=True, lazy_filter=True, backward_on_calling_thread=True):
+            densify=True, rebind=True, lazy_filter=True, backward_on_calling_thread="auto"):
     """gaussian_renderer, loss: the reference's modules (or None to leave alone); gaussian_model: its GaussianModel class or
     the module that defines it.  lazy_filter: the visibility filter the replaced render returns keeps the caller's masked
-    max-radii update on the device (_VisFilter above); False = a plain bool tensor.  backward_on_calling_thread:
-    torch.autograd.set_multithreading_enabled(False) until uninstall() -- `loss.backward()` then runs its nodes on the thread
+    max-radii update on the device (_VisFilter above); False = a plain bool tensor.  backward_on_calling_thread ("auto": only
+    when no other Python thread exists at the time of the call; True / False force it):
+    torch.autograd.set_multithreading_enabled(False), a PROCESS-WIDE setting, until uninstall() -- `loss.backward()` then runs its nodes on the thread
     that called it instead of handing them to the autograd engine's device thread and waiting: on this path (a few dozen
     short nodes per iteration, every one of them only ENQUEUES work) the hand-off and the two threads' turns at the
     interpreter lock cost more than the nodes -- the unchanged loop at 1 M Gaussians / 512^2 went 2.09 -> 1.28 ms per iteration
@@ -196,6 +197,13 @@ def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=Tr
     cls = getattr(gaussian_model, "GaussianModel", gaussian_model)
     h = _Handle()
     h.multithreading = None
+    if backward_on_calling_thread == "auto":
+        # PROCESS-WIDE switch (until uninstall()): right for the reference's single-threaded loop, a trap for a caller that runs
+        # backward passes from threads of its own -- "auto" only takes it when this is the only Python thread at install time;
+        # pass True / False to decide yourself
+        import threading
+        backward_on_calling_thread = threading.active_count() == 1
+    h.backward_on_calling_thread = bool(backward_on_calling_thread)
     if backward_on_calling_thread and hasattr(torch.autograd, "set_multithreading_enabled"):
         h.multithreading = torch.autograd.is_multithreading_enabled()
         torch.autograd.set_multithreading_enabled(False)

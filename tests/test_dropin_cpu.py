@@ -48,7 +48,17 @@ def test_install_replaces_rebinds_falls_through_and_uninstall_restores():
         orig = (gr.render, ls.l1_loss, ls.ssim, gm.GaussianModel.training_setup, gm.GaussianModel.add_densification_stats,
                 gm.GaussianModel.densify_and_prune)
         assert torch.autograd.is_multithreading_enabled()
-        h = luciddreamer_amd.install(gr, ls, gm)
+        # "auto" (the default) leaves the PROCESS-WIDE autograd setting alone when the caller has threads of its own
+        import threading
+        stop = threading.Event()
+        t = threading.Thread(target=stop.wait, daemon=True)
+        t.start()
+        h0 = luciddreamer_amd.install(gr, ls, gm)
+        assert torch.autograd.is_multithreading_enabled() and not h0.backward_on_calling_thread
+        luciddreamer_amd.uninstall(h0)
+        stop.set()
+        t.join()
+        h = luciddreamer_amd.install(gr, ls, gm, backward_on_calling_thread=True)
         assert not torch.autograd.is_multithreading_enabled()                         # backward on the calling thread while installed
         assert gr.render is not orig[0] and caller.render is gr.render               # re-bound in the module that imported it by name
         assert caller.l1_loss is ls.l1_loss and caller.ssim is ls.ssim and ls.l1_loss is not orig[1]
