@@ -117,7 +117,10 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
 /*
  * Backward.  R is the value lr_forward returned and binning_capacity the value it was given
  * (exact mode: R >= 0, capacity 0; async mode: R = LR_NUM_RENDERED_ON_DEVICE, capacity > 0; no host
- * synchronisation happens in either mode -- use lr_check to learn about an overflow).  dL_depths is accepted and ignored, exactly as the reference does
+ * synchronisation happens in either mode -- use lr_check to learn about an overflow).  As in the reference, whose backward lays the
+ * binning state out from R (rasterizer_impl.cu:364-366), these two values ARE used: they bound the number of list segments the
+ * blend backward launches workgroups for (one per 256 instances of a tile's list beyond its first 256).
+ * dL_depths is accepted and ignored, exactly as the reference does
  * (RAST/cuda_rasterizer/backward.cu:457-464, 539-554 are commented out).
  * accumulate_mask: bit k set (LR_ACC_*) => that output is ACCUMULATED into (rows of visible Gaussians are
  * added to the existing contents, rows of culled Gaussians are not touched); bit clear => the output is

@@ -609,6 +609,25 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
         e += gridDim.x - (uint32_t)grid_tiles;                                                                              \
         lds_barrier();                                  /* the next item stages into the same LDS */                        \
     }
+// The same without the stride loop: workgroup grid_tiles + e takes listed segment e and nothing else.  For the one-wave-per-tile
+// shape, whose 64-register budget the loop costs three more spilled dwords per lane (+6 % at C3, profiles/r05e_pmc_c3.json).  The
+// launch must then cover every listed segment: it does whenever the caller hands lr_backward the R / binning_capacity of its
+// forward, as the reference's own backward requires of R (rasterizer_impl.cu:364-366: the binning state is laid out from it).
+#define LR_BWD_KERNEL_BODY_ONE(ITEM)                                                                                        \
+    if (hdr->overflow != 0u) return;                                                                                        \
+    int tile, seg = seg_on ? 0 : -1;                                                                                        \
+    uint32_t slot = 0u;                                                                                                     \
+    if ((int)blockIdx.x < grid_tiles) {                                                                                     \
+        tile = blend_tile(tile_map, num_tiles);                                                                             \
+        if (tile < 0) return;                                                                                               \
+        if (seg_on) slot = tile_seg0[tile];                                                                                 \
+    } else {                                                                                                                \
+        const uint32_t e = blockIdx.x - (uint32_t)grid_tiles;                                                               \
+        if (e >= hdr->n_seg) return;                                                                                        \
+        const uint2 ts = reinterpret_cast<const uint2*>(bin_base + bin_layout((long long)hdr->bin_bound).seg_list)[e];      \
+        tile = (int)ts.x; seg = (int)ts.y; slot = e + 1u;                                                                   \
+    }                                                                                                                       \
+    ITEM(tile, seg, slot, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check);
 #define LR_BWD_SEG_PARAMS LR_BWD_PARAMS, const uint32_t* __restrict__ tile_seg0, int grid_tiles, int seg_on
 
 // 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
@@ -628,7 +647,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), 
 k_render_bwd_tile(LR_BWD_SEG_PARAMS)
 {
 #define LR_ITEM render_bwd_tile<44, STRICT>
-    LR_BWD_KERNEL_BODY(LR_ITEM)
+    LR_BWD_KERNEL_BODY_ONE(LR_ITEM)
 #undef LR_ITEM
 }
 // the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
@@ -707,7 +726,9 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     // knows, capped (a workgroup strides over the list, so the cap costs nothing but balance on absurdly long lists).
     static const int forced_seg = [] { const char* e = getenv("LR_BWD_SEG"); return e ? atoi(e) : -1; }();
     const int seg_on = (tune_get(TUNE_BWD_SEG) >= 0 ? tune_get(TUNE_BWD_SEG) : (forced_seg >= 0 ? forced_seg : 1)) != 0 ? 1 : 0;
-    const int extra = seg_on ? (int)(seg_bound < 1 ? 1 : seg_bound > 262144 ? 262144 : seg_bound) : 0;
+    // (the one-wave-per-tile shape takes exactly one listed segment per workgroup: no cap there)
+    const long long cap = shape == BLEND_TILE ? 0x3fffffffll : 262144ll;
+    const int extra = seg_on ? (int)(seg_bound < 1 ? 1 : seg_bound > cap ? cap : seg_bound) : 0;
     const dim3 g(grid + extra);
 #define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, grid, seg_on
     if (shape == BLEND_TILE) {
