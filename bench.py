@@ -616,8 +616,18 @@ def measure_f_rows(dev):
         m._opacity, m._scaling, m._rotation = mk(P, 1), mk(P, 3), mk(P, 4)
         m.percent_dense = 0.01
         m.optimizer = FusedAdam([{"params": [getattr(m, a)], "lr": 1e-3, "name": n} for n, a in D.GROUP_ATTR.items()], lr=0.0, eps=1e-15)
+        for n_, a in D.GROUP_ATTR.items():
+            t_ = getattr(m, a)
+            t_.grad = torch.zeros_like(t_) if n_ == "f_rest" else torch.randn_like(t_) * 1e-3
+        # first as LucidDreamer's first thousand iterations see it: active SH degree 0, the 45 coefficients of features_rest
+        # have zero gradient and zero moments -- lr_adam_step reads them (16 B) and stores nothing; then with every gradient
+        # non-zero (28 B per element)
+        ms0 = event_ms(lambda: m.optimizer.step(), 10)
+        b0 = P * (14 * 7 + 45 * 4) * 4
+        out["adam_step_3M_active_sh_degree_0"] = {"us": round(ms0 * 1e3, 1), "algorithmic_bytes": b0,
+                                                  "frac": round(b0 / (ms0 * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}
         for a in D.GROUP_ATTR.values():
-            getattr(m, a).grad = torch.zeros_like(getattr(m, a))
+            getattr(m, a).grad = torch.randn_like(getattr(m, a)) * 1e-3
         ms = event_ms(lambda: m.optimizer.step(), 10)
         b = P * 59 * 4 * 7                                      # read parameter, gradient, two moments; write parameter, two moments
         out["adam_step_3M"] = {"us": round(ms * 1e3, 1), "algorithmic_bytes": b, "frac": round(b / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4)}

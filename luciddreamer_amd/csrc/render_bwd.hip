@@ -726,9 +726,11 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     // knows, capped (a workgroup strides over the list, so the cap costs nothing but balance on absurdly long lists).
     static const int forced_seg = [] { const char* e = getenv("LR_BWD_SEG"); return e ? atoi(e) : -1; }();
     const int seg_on = (tune_get(TUNE_BWD_SEG) >= 0 ? tune_get(TUNE_BWD_SEG) : (forced_seg >= 0 ? forced_seg : 1)) != 0 ? 1 : 0;
-    // (the one-wave-per-tile shape takes exactly one listed segment per workgroup: no cap there)
+    // (the one-wave-per-tile shape takes exactly one listed segment per workgroup: no cap there, and it is not used when the
+    // caller gave no usable bound -- seg_bound < 0, see lr_backward -- or when segments are off and its workgroup walks the whole list)
+    if (shape == BLEND_TILE && seg_on && seg_bound < 0) shape = BLEND_HALF;
     const long long cap = shape == BLEND_TILE ? 0x3fffffffll : 262144ll;
-    const int extra = seg_on ? (int)(seg_bound < 1 ? 1 : seg_bound > cap ? cap : seg_bound) : 0;
+    const int extra = seg_on ? (int)(seg_bound < 1 ? 1024 : seg_bound > cap ? cap : seg_bound) : 0;
     const dim3 g(grid + extra);
 #define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, grid, seg_on
     if (shape == BLEND_TILE) {

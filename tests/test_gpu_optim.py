@@ -100,3 +100,38 @@ def test_works_with_device_densification(hip_device):
         getattr(m, a).grad = torch.ones_like(getattr(m, a))
     m.optimizer.step()                                        # moments follow the re-pointed parameters
     assert int(m.optimizer.state[m._xyz]["step"]) == 2
+
+
+def test_coefficients_above_the_active_sh_degree_stay_untouched_and_equal_torch(hip_device):
+    """LucidDreamer raises the SH degree every 1000 of its 2990 iterations: the coefficients above the active degree have zero
+    gradient and zero moments throughout, and lr_adam_step skips their stores (adam.hip: the update of such an element is the
+    identity, signed zeros included).  Against torch.optim.Adam over 12 steps with the degree going 0 -> 1 on the way: bit-equal
+    parameters where nothing ever arrived, the usual few ulps elsewhere, and moments that start from zero when a band wakes up."""
+    from luciddreamer_amd.optim import FusedAdam
+    P = 20_000
+    a, b = _params(P, hip_device, 3), _params(P, hip_device, 3)
+    with torch.no_grad():
+        for d in (a, b):
+            d["f_rest"][:, 7:, 1] = -0.0                                       # signed zeros among the parameters themselves
+    start = b["f_rest"].detach().clone()
+    groups = lambda d: [{"params": [d[k]], "lr": LRS[k], "name": k} for k in SHAPES]
+    ref = torch.optim.Adam(groups(a), lr=0.0, eps=1e-15)
+    fus = FusedAdam(groups(b), lr=0.0, eps=1e-15)
+    g = torch.Generator().manual_seed(4)
+    for it in range(12):
+        active = 0 if it < 6 else 3                                            # coefficients of f_rest that receive a gradient
+        for k in SHAPES:
+            grad = torch.randn((P,) + SHAPES[k], generator=g).to(hip_device)
+            if k == "f_rest":
+                grad[:, active:, :] = 0
+            a[k].grad, b[k].grad = grad.clone(), grad.clone()
+        ref.step()
+        fus.step()
+    assert torch.equal(b["f_rest"][:, 3:, :], start[:, 3:, :])                 # never touched: the same bits, -0.0 included
+    assert torch.equal(a["f_rest"][:, 3:, :], start[:, 3:, :])                 # ... as with torch's own arithmetic
+    for k in SHAPES:
+        close = lambda x, y: (x - y).abs().max().item() <= 2e-6 * max(y.abs().max().item(), 1e-30)
+        assert close(b[k], a[k]), k
+        sa, sb = ref.state[a[k]], fus.state[b[k]]
+        assert close(sb["exp_avg"], sa["exp_avg"]) and close(sb["exp_avg_sq"], sa["exp_avg_sq"]), k
+    assert float(fus.state[b["f_rest"]]["exp_avg_sq"][:, 3:, :].abs().max()) == 0.0

@@ -352,3 +352,57 @@ def test_forward_candidate_pairs_give_the_same_bits(hip_device, P, W, H, scale_m
     assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
     for k in a["grads"]:
         assert np.array_equal(a["grads"][k], b["grads"][k]), k
+
+
+def _stack_cloud(n, W, H, cam, px, py, opacity, seed):
+    """n small Gaussians stacked behind pixel (px, py) at increasing depths (jittered by a pixel or two): one tile whose list is
+    exactly n long -- the segment boundaries of the blend backward (common.h BWD_SEG = 256) at chosen positions."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    tfx, tfy = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+    z = torch.linspace(2.0, 6.0, n)
+    jx = px + (torch.rand(n, generator=g) - 0.5) * 3.0
+    jy = py + (torch.rand(n, generator=g) - 0.5) * 3.0
+    x = ((jx + 0.5) * 2.0 / W - 1.0) * tfx * z
+    y = ((jy + 0.5) * 2.0 / H - 1.0) * tfy * z
+    focal = W / (2.0 * tfx)
+    sig = (1.0 + torch.rand(n, generator=g)) * z / focal                     # 1-2 pixels of standard deviation on the screen
+    scales = torch.stack([sig, sig * (0.6 + 0.8 * torch.rand(n, generator=g)), sig], dim=1)
+    q = torch.randn(n, 4, generator=g)
+    shs = torch.zeros(n, 16, 3)
+    shs[:, 0, :] = (torch.rand(n, 3, generator=g) - 0.5) / 0.28209479177387814
+    shs[:, 1:, :] = 0.05 * torch.randn(n, 15, 3, generator=g)
+    return dict(means3D=torch.stack([x, y, z], dim=1).float().contiguous(), scales=scales.float().contiguous(),
+                rotations=(q / q.norm(dim=1, keepdim=True)).float().contiguous(),
+                opacities=torch.full((n, 1), float(opacity)), shs=shs.float().contiguous())
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2])
+@pytest.mark.parametrize("opacity", [0.006, 0.08])      # nobody stops early / the centre pixels stop inside the first segment
+@pytest.mark.parametrize("n", [255, 256, 257, 511, 512, 513, 700])
+def test_list_segments_at_their_boundaries(hip_device, shape, opacity, n):
+    """A tile whose list is exactly n long for n around the multiples of the segment length: no segment (256), a segment of one
+    element (257, 513), whole segments (512), a ragged last one (700) -- against the whole-list walk and against the oracle, with
+    pixels that never stop and with pixels that stop in front of the first checkpoint."""
+    W, H = 64, 48
+    cam = cameras.identity_camera(W, H)
+    cloud = _stack_cloud(n, W, H, cam, 40.0, 24.0, opacity, seed=n)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.2, 0.4, 0.1])
+    _lib.tune_set("blend_quad", shape)
+    try:
+        outs = []
+        for seg in (0, 1):
+            _lib.tune_set("bwd_seg", seg)
+            outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
+    finally:
+        _lib.tune_set("bwd_seg", -1)
+        _lib.tune_set("blend_quad", -1)
+    whole, segs = outs
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    hp.compare_forward(segs, ref)
+    for k in ("means2D", "opacity", "means3D", "sh", "scales", "rotations"):
+        a, b = whole["grads"][k], segs["grads"][k]
+        scale = float(np.abs(a).max())
+        assert scale > 0 and float(np.abs(a - b).max()) <= 4e-6 * scale, (k, float(np.abs(a - b).max()) / scale)
+    hp.compare_grads(segs["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
