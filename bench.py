@@ -981,19 +981,23 @@ def run_cpu_baseline(wl):
             # the UNCHANGED loop again after ONE call, luciddreamer_amd.install(R): render_raw, the paired l1 / ssim pass,
             # FusedAdam and the fused densification statistics are switched in underneath the reference's own names
             import luciddreamer_amd
-            for policy, key, what in (
+            for policy, key, what, active in (
                     ("verify", "this_rasterizer_after_install",
-                     "the same unchanged loop after luciddreamer_amd.install(reference modules): one call, no edits to the caller"),
+                     "the same unchanged loop after luciddreamer_amd.install(reference modules): one call, no edits to the caller", None),
                     ("drop", "this_rasterizer_after_install_policy_drop",
                      "the same with config.set_async(True, on_overflow='drop'): the forward does not wait for its own header (a view "
-                     "that needs more than 1.3 x the instances of any view before it is warned about and contributes no gradient)")):
+                     "that needs more than 1.3 x the instances of any view before it is warned about and contributes no gradient)", None),
+                    ("verify", "this_rasterizer_after_install_active_sh_degree_0",
+                     "the installed loop as LucidDreamer's FIRST thousand iterations run it: active SH degree 0 of 3 (R/luciddreamer.py:"
+                     "287-288 raises it every 1000 of 2990 iterations; every leg above runs degree 3 from the start) -- the 45 "
+                     "coefficients of features_rest receive no gradient and the Adam step stores nothing for them", 0)):
                 config.reset()
                 config.set_async(True, on_overflow=policy)
                 for _pass in range(2):
                     with ref_loop.stack("ours") as (R, dev):
                         handle = luciddreamer_amd.install(R, backward_on_calling_thread=True)    # the single-threaded loop: what "auto" picks there
                         try:
-                            gm = ref_loop.model_from_cloud(R, base, dev)
+                            gm = ref_loop.model_from_cloud(R, base, dev, active_sh_degree=active)
                             cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)
                             torch.cuda.synchronize()
                             t0 = time.perf_counter()
