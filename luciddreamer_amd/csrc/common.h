@@ -138,7 +138,7 @@ inline GeomLayout geom_layout(int P) {
     L.total = o;
     return L;
 }
-struct ImgLayout { size_t final_T, n_contrib, ranges, part_hist, bin_total, bin_start, big_queue, tile_seg0, total; };
+struct ImgLayout { size_t final_T, n_contrib, ranges, part_hist, bin_total, bin_start, big_queue, tile_seg0, c_final, total; };
 inline ImgLayout img_layout(int W, int H) {
     ImgLayout L; size_t o = 0; size_t N = (size_t)W * H; if (N == 0) N = 1;
     size_t T = (size_t)((W + TILE_X - 1) / TILE_X) * ((H + TILE_Y - 1) / TILE_Y); if (T == 0) T = 1;
@@ -154,13 +154,17 @@ inline ImgLayout img_layout(int W, int H) {
     L.bin_start = o; o += align_up(bins * 4);
     L.big_queue = o; o += align_up((bins + 1) * 4);
     L.tile_seg0 = o; o += align_up(T * 4);           // first seg_list slot of each tile (written by the blend forward for tiles longer than BWD_SEG)
+    L.c_final = o;   o += align_up(N * 16);          // final colour (background included) per pixel, written by the blend forward for the
+                                                     // pixels of tiles longer than BWD_SEG only: what the backward's later segments subtract the
+                                                     // checkpoint's colour-so-far from (allocation only for every other tile)
     L.total = o;
     return L;
 }
 // Segments of a tile's list.  The blend backward is a recursion along the list, but each stretch of BWD_SEG positions can
 // start on its own once it knows, per pixel, the transmittance in front of its deepest layer and the colour behind it: the
-// blend forward leaves both at every BWD_SEG-th position it reaches (`ckpt`: one float4 {T, colour still to come . rgb} per
-// pixel of the tile; pixel index = quadrant * 64 + lane of the forward) and lists the (tile, segment) pairs beyond each
+// blend forward leaves {T, colour so far} at every BWD_SEG-th position it reaches (`ckpt`: one float4 per pixel of the tile;
+// pixel index = quadrant * 64 + lane of the forward) and the pixel's final colour in ImgLayout::c_final -- the colour still to
+// come behind the position is their difference -- and lists the (tile, segment) pairs beyond each
 // tile's first segment in `seg_list` (slots reserved with one atomic per tile on GeomHeader::n_seg).  The backward runs one
 // workgroup per tile for the first segment and one per listed pair: long lists (hundreds to thousands of instances per
 // tile on small images and dense clouds) no longer make the kernel as slow as its longest tile.
@@ -420,12 +424,12 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
-                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, hipStream_t s);
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final, hipStream_t s);
 // seg_bound: upper bound of GeomHeader::n_seg known to the host (bin_seg_capacity of the instance bound of the call)
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
-                       const uint32_t* tile_seg0, long long seg_bound, hipStream_t s);
+                       const uint32_t* tile_seg0, const float4* c_final, long long seg_bound, hipStream_t s);
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                       const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,

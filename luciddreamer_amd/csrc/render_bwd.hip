@@ -182,7 +182,7 @@ __device__ __forceinline__ void bwd_pixel(BwdPix& p, const float qA, const float
 // with seg < 0, the whole list.  ck_slot: the checkpoint the forward left at the segment's deep end (common.h BinLayout::ckpt).
 template <bool QUAD, bool MERGE, bool STRICT>
 __device__ __forceinline__ void render_bwd_item(const int tile, const int seg, const uint32_t ck_slot,
-             int W, int H, int gx, const uint2* __restrict__ ranges,
+             const float4* __restrict__ c_final, int W, int H, int gx, const uint2* __restrict__ ranges,
              const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, const float* __restrict__ final_Ts,
              const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -238,19 +238,19 @@ __device__ __forceinline__ void render_bwd_item(const int tile, const int seg, c
     PB.A = bg[0] * PB.dLr + bg[1] * PB.dLg + bg[2] * PB.dLb;
     if (seg_hi < total) {
         // The recursion starts in the middle of the list.  A pixel the forward was still blending at position seg_hi
-        // (last > seg_hi: it stopped later, or never) takes the forward's own T there and the colour still to come behind it
-        // from the checkpoint (render_fwd.hip); a pixel that had stopped by then starts as at the list's end (final T,
+        // (last > seg_hi: it stopped later, or never) takes the forward's own T there and the colour still to come behind it --
+        // its final colour minus the checkpoint's colour so far (render_fwd.hip); a pixel that had stopped by then starts as at the list's end (final T,
         // background behind it): every position of this segment at or behind its `last` is skipped anyway.
         const int qA = QUAD ? w : 2 * w;                         // quadrant of pixel A (pixel index of the checkpoint: quadrant * 64 + lane)
         if (PA.last > (uint32_t)seg_hi) {
-            const float4 c = ck[qA * 64 + l];
+            const float4 c = ck[qA * 64 + l], f = c_final[pixA];       // {T, colour so far} there; the pixel's final colour
             PA.T = c.x;
-            PA.A = (c.y * PA.dLr + c.z * PA.dLg + c.w * PA.dLb) * __builtin_amdgcn_rcpf(c.x);
+            PA.A = ((f.x - c.y) * PA.dLr + (f.y - c.z) * PA.dLg + (f.z - c.w) * PA.dLb) * __builtin_amdgcn_rcpf(c.x);
         }
         if (!QUAD && PB.last > (uint32_t)seg_hi) {
-            const float4 c = ck[(qA + 1) * 64 + l];
+            const float4 c = ck[(qA + 1) * 64 + l], f = c_final[pixB];
             PB.T = c.x;
-            PB.A = (c.y * PB.dLr + c.z * PB.dLg + c.w * PB.dLb) * __builtin_amdgcn_rcpf(c.x);
+            PB.A = ((f.x - c.y) * PB.dLr + (f.y - c.z) * PB.dLg + (f.z - c.w) * PB.dLb) * __builtin_amdgcn_rcpf(c.x);
         }
     }
     const uint32_t lastL = wave_max_u32(PA.last), lastR = QUAD ? 0u : wave_max_u32(PB.last);   // per quadrant
@@ -413,7 +413,7 @@ __device__ __forceinline__ void render_bwd_item(const int tile, const int seg, c
 // workgroups: 8160 of them at 1080p, no partner wave to wait for at the batch barriers.
 template <int BATCH, bool STRICT>
 __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, const uint32_t ck_slot,
-                  int W, int H, int gx, const uint2* __restrict__ ranges,
+                  const float4* __restrict__ c_final, int W, int H, int gx, const uint2* __restrict__ ranges,
                   const uint32_t* __restrict__ point_list, const GaussRec* __restrict__ rec,
                   const float* __restrict__ bg, const float* __restrict__ final_Ts,
                   const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpix,
@@ -458,9 +458,9 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
         p.dLb = ins ? dL_dpix[2 * N + pix] : 0.f;
         p.A = bg0 * p.dLr + bg1 * p.dLg + bg2 * p.dLb;
         if (seg_hi < total && p.last > (uint32_t)seg_hi) {          // as render_bwd_item: the forward's state at the segment's deep end
-            const float4 c = ck[q * 64 + l];
+            const float4 c = ck[q * 64 + l], f = c_final[pix];
             p.T = c.x;
-            p.A = (c.y * p.dLr + c.z * p.dLg + c.w * p.dLb) * __builtin_amdgcn_rcpf(c.x);
+            p.A = ((f.x - c.y) * p.dLr + (f.y - c.z) * p.dLg + (f.z - c.w) * p.dLb) * __builtin_amdgcn_rcpf(c.x);
         }
     };
     load_pixel(P0, pxL, pyT, 0); load_pixel(P1, pxR, pyT, 1); load_pixel(P2, pxL, pyB, 2); load_pixel(P3, pxR, pyB, 3);
@@ -604,7 +604,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
             const uint2 ts = seg_list[e];               /* slot e holds segment ts.y; the checkpoint at its deep end: e + 1 */ \
             tile = (int)ts.x; seg = (int)ts.y; slot = e + 1u;                                                               \
         }                                                                                                                   \
-        ITEM(tile, seg, slot, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check); \
+        ITEM(tile, seg, slot, c_final, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check); \
         if (!listed) break;                                                                                                 \
         e += gridDim.x - (uint32_t)grid_tiles;                                                                              \
         lds_barrier();                                  /* the next item stages into the same LDS */                        \
@@ -627,8 +627,8 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
         const uint2 ts = reinterpret_cast<const uint2*>(bin_base + bin_layout((long long)hdr->bin_bound).seg_list)[e];      \
         tile = (int)ts.x; seg = (int)ts.y; slot = e + 1u;                                                                   \
     }                                                                                                                       \
-    ITEM(tile, seg, slot, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check);
-#define LR_BWD_SEG_PARAMS LR_BWD_PARAMS, const uint32_t* __restrict__ tile_seg0, int grid_tiles, int seg_on
+    ITEM(tile, seg, slot, c_final, W, H, gx, ranges, point_list, rec, bg, final_Ts, n_contrib, dL_dpix, bin_base, hdr, force_check);
+#define LR_BWD_SEG_PARAMS LR_BWD_PARAMS, const uint32_t* __restrict__ tile_seg0, const float4* __restrict__ c_final, int grid_tiles, int seg_on
 
 // 7 waves per SIMD (<= 72 VGPRs); the QUAD shape's 32 KB of LDS per workgroup allow 4 workgroups = 4 waves per SIMD
 template <bool QUAD, bool MERGE, bool STRICT = false>
@@ -700,7 +700,7 @@ int blend_shape(int num_tiles)
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
-                       const uint32_t* tile_seg0, long long seg_bound, hipStream_t s)
+                       const uint32_t* tile_seg0, const float4* c_final, long long seg_bound, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
@@ -732,7 +732,7 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const long long cap = shape == BLEND_TILE ? 0x3fffffffll : 262144ll;
     const int extra = seg_on ? (int)(seg_bound < 1 ? 1024 : seg_bound > cap ? cap : seg_bound) : 0;
     const dim3 g(grid + extra);
-#define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, grid, seg_on
+#define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, c_final, grid, seg_on
     if (shape == BLEND_TILE) {
         if (strict) hipLaunchKernelGGL(k_render_bwd_tile<true>, g, dim3(64), 0, s, LR_SEG_ARGS);
         else if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, g, dim3(64), 0, s, LR_SEG_ARGS);

@@ -100,7 +100,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
              GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,
-             uint32_t* __restrict__ tile_seg0)
+             uint32_t* __restrict__ tile_seg0, float4* __restrict__ c_final)
 {
     __shared__ float4 s_q0[BATCH];      // x, y, Ap = -0.5 conic a, Bp = -conic b      (common.h gauss_power; x log2 e)
     __shared__ float4 s_q1[BATCH];      // Cp = -0.5 conic c (x log2 e), opacity, depth, qmax (cull threshold, x log2 e)
@@ -128,7 +128,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 
     // A list longer than BWD_SEG is cut into segments for the backward (common.h BinLayout::seg_list / ckpt): one atomic
     // reserves the tile's slots, the (tile, segment) pairs are listed, and at the top of every later staging round the
-    // waves still blending leave {T, colour so far} of their pixels -- turned into {T, colour still to come} at the end
+    // waves still blending leave {T, colour so far} of their pixels; the final colour goes to c_final at the end
     static_assert(BATCH == BWD_SEG, "a staging round of the forward is one segment of the backward");
     const int n_seg = total > 0 ? (total - 1) / BWD_SEG : 0;
     uint32_t seg0 = 0;
@@ -225,23 +225,18 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
         }
     }
 
-    if (n_ck > 0) {
-        // colour still to come behind each checkpoint = final colour (background included) - colour so far
-        const float fr = A.Cr + A.T * bg[0], fg = A.Cg + A.T * bg[1], fb = A.Cb + A.T * bg[2];
-        for (int g = 0; g < n_ck; g++) {
-            float4* c = ckpt + (size_t)(seg0 + g) * TILE_PIX + tid;
-            const float4 v = *c;
-            *c = make_float4(v.x, fr - v.y, fg - v.z, fb - v.w);
-        }
-    }
     if (inside) {
         const size_t N = (size_t)W * H;
         const size_t pix = (size_t)py * W + px;
         final_T[pix] = A.T;
         n_contrib[pix] = __builtin_amdgcn_inverse_ballot_w64(done) ? A.last : (uint32_t)total;
-        out_color[pix] = A.Cr + A.T * bg[0];
-        out_color[N + pix] = A.Cg + A.T * bg[1];
-        out_color[2 * N + pix] = A.Cb + A.T * bg[2];
+        const float fr = A.Cr + A.T * bg[0], fg = A.Cg + A.T * bg[1], fb = A.Cb + A.T * bg[2];
+        out_color[pix] = fr;
+        out_color[N + pix] = fg;
+        out_color[2 * N + pix] = fb;
+        // a segmented tile: the final colour once more, where the backward's later segments find it (they subtract a
+        // checkpoint's colour-so-far from it: the colour still to come behind that position, background included)
+        if (n_seg > 0) c_final[pix] = make_float4(fr, fg, fb, 0.f);
         out_depth[pix] = (A.acc > 0.5f) ? A.D / A.acc : 0.0f;         // forward.cu:384-388
     }
 }
@@ -251,7 +246,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
-                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, hipStream_t s)
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
@@ -262,7 +257,7 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const bool strict = tune_get(TUNE_STRICT) > 0;
 #define LR_FWD(S, PR) hipLaunchKernelGGL((k_render_fwd<S, PR>), dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, \
                                          point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr,   \
-                                         seg_list, ckpt, tile_seg0)
+                                         seg_list, ckpt, tile_seg0, c_final)
     if (strict) { if (pair) LR_FWD(true, true); else LR_FWD(true, false); }
     else { if (pair) LR_FWD(false, true); else LR_FWD(false, false); }
 #undef LR_FWD
