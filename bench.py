@@ -21,6 +21,8 @@ Workloads (BASELINE.json configs):
       V = 30 views per rank per step.
   c2: 1e5 Gaussians, box cloud, identity view.  c3box: the dense reading of C3 (all 1e6 Gaussians in view).
   c4shape: 3e6 Gaussians at 2560x1440, all in view.  c5shape: 1e6 Gaussians at 512x512, all in view.
+  ld512: 1e6 pixel-sized Gaussians in one layer on a panorama band, 512x512 views of the rotate360 path (LucidDreamer's own
+      scene statistics: a quarter of the cloud in view, about one Gaussian per pixel).
 
 Prints ONE JSON line (rank 0).  `value` is the headline entry point (one lr_views_accumulate call per step, async mode,
 3 streams).  In the default run (N = 1, workload c3) the same process also times, with the same K and W,
@@ -54,6 +56,9 @@ WORKLOADS = {
     "c3box": ("box", 1_000_000, (1920, 1080), 30, "C3-box (all Gaussians in front of the camera)"),
     "c4shape": ("box", 3_000_000, (2560, 1440), 6, "C4-shape (all Gaussians in front of the camera)"),
     "c5shape": ("box", 1_000_000, (512, 512), 30, "C5-shape (all Gaussians in front of the camera)"),
+    # LucidDreamer's own scene statistics (luciddreamer_amd/synthetic.py kind "shell"): one layer of pixel-sized Gaussians
+    # lifted from a panorama, a quarter of them in a 512 x 512 view of the rotate360 path, about one per pixel
+    "ld512": ("shell", 1_000_000, (512, 512), 30, "LD-512 (one layer of pixel-sized Gaussians on a panorama band)"),
 }
 
 
@@ -109,10 +114,10 @@ class Workload:
         total = V * world if scaling == "weak" else V
         mine = parallel.shard_views(total, rank, world)
         per = f"{V} views/rank/step" if scaling == "weak" else f"{V} views/step over {world} rank(s)"
-        if kind == "band":
+        if kind in ("band", "shell"):
             path = cameras.rotate360_path(W, H, n_views=total)
             my_cams = [path[i] for i in mine]
-            self.label = f"{tag}: {P} Gaussians, SH degree {self.degree}, {W}x{H}, band cloud, rotate360 path, {per}"
+            self.label = f"{tag}: {P} Gaussians, SH degree {self.degree}, {W}x{H}, {kind} cloud, rotate360 path, {per}"
         else:
             my_cams = [cameras.identity_camera(W, H)] * len(mine)
             self.label = f"{tag}: {P} Gaussians, SH degree {self.degree}, {W}x{H}, box cloud, identity view, {per}"
@@ -812,7 +817,7 @@ def main():
         other = {}
         del wl
         torch.cuda.empty_cache()
-        for name in ("c2", "c3box", "c4shape", "c5shape"):
+        for name in ("c2", "c3box", "c4shape", "c5shape", "ld512"):
             w2 = Workload(name, args, rank, world, dev)
             steps2 = max(2, min(args.steps, 5)) * (4 if name == "c2" else 1)
             v, ms, host, _ = run_leg(w2, "views", False, args.streams, steps2, 1, world, dev, fused)

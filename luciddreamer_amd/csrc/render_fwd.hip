@@ -91,7 +91,9 @@ __device__ __forceinline__ void fwd_step(PixState& p, uint64_t& done, const floa
 // PAIR: the candidate loop takes two candidates per round (small images: few waves per SIMD, the kernel time is the longest
 // wave's dependent chain -- LDS read, exponent, v_exp, the T recursion -- and two candidates' chains overlap except for the
 // recursion itself; profiles/r05a_pmc_c5shape.json: VALU busy 49 %, 2.2 waves resident per SIMD on average at 512^2).
-// Same operations per pixel and candidate in the same order: bit-identical images.
+// Same operations per pixel and candidate in the same order: bit-identical images.  Per tile: only lists of PAIR_MIN_LIST and more
+// (measured, forward alone: dense 512^2, 1 700 per tile, 180 -> 173 us; one layer of pixel-sized splats, 320 per tile, 53.7 -> 55.1).
+constexpr int PAIR_MIN_LIST = 1024;
 template <bool STRICT, bool PAIR>
 __global__ void __launch_bounds__(THREADS)
 k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
@@ -183,7 +185,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             uint64_t mask = __ballot(hit);
             // BLEND: walk the candidates in list order (a non-candidate is exactly the reference's `continue`: no pixel of
             // the quadrant can reach alpha >= 1/255)
-            if constexpr (PAIR) {
+            if (PAIR && total >= PAIR_MIN_LIST) {
                 while (mask) {
                     const int k0 = __ffsll((long long)mask) - 1;
                     mask &= mask - 1;

@@ -18,6 +18,7 @@ def make_cloud(P: int, kind: str = "box", seed: int = 0, sh_coeffs: int = 16,
     kind == "box":  xyz = U(-1,1)^3 * (2.0, 1.2, 1.5) + (0,0,4)   (single view down +z)
     kind == "band": azimuth U(0,2pi), elevation U(-0.35,0.35), radius U(2,6) (camera paths
                     that rotate about the origin see a similar load from every direction)
+    kind == "shell": one layer of pixel-sized Gaussians on a band around the origin (LucidDreamer's own scene statistics)
     """
     g = torch.Generator().manual_seed(seed)
     if kind == "box":
@@ -30,10 +31,23 @@ def make_cloud(P: int, kind: str = "box", seed: int = 0, sh_coeffs: int = 16,
         means = torch.stack([rad * torch.cos(el) * torch.sin(az),
                              rad * torch.sin(el),
                              rad * torch.cos(el) * torch.cos(az)], dim=1)
+    elif kind == "shell":
+        # The statistics of LucidDreamer's own scenes (R/luciddreamer.py: a point cloud lifted from RGB-D views of a panorama,
+        # R/scene/gaussian_model.py:126-147 create_from_pcd: one isotropic Gaussian per point, its scale the distance to its
+        # neighbours): ONE layer of points on a band around the camera, as dense as the pixels of a 512 x 512 view (a view of
+        # the rotate360 path sees a quarter of them, about one per pixel), each about a pixel wide.
+        az = torch.rand(P, generator=g) * (2.0 * math.pi)
+        zz = (torch.rand(P, generator=g) * 2.0 - 1.0) * 0.3333                  # uniform in area on the band |sin(elevation)| < 1/3
+        rad = 3.0 + 0.8 * torch.sin(3.0 * az) * torch.cos(5.0 * zz) + 0.05 * torch.randn(P, generator=g)
+        c = torch.sqrt(1.0 - zz * zz)
+        means = torch.stack([rad * c * torch.sin(az), rad * zz, rad * c * torch.cos(az)], dim=1)
+        spacing = rad * math.sqrt(4.19 / float(max(P, 1)))                       # neighbour distance: band area 4.19 sr
+        scales = (spacing * scale_mult).unsqueeze(1) * torch.exp(0.15 * torch.randn(P, 3, generator=g))
     else:
         raise ValueError(f"unknown cloud kind {kind!r}")
     s0 = 0.5 * float(max(P, 1)) ** (-1.0 / 3.0) * scale_mult
-    scales = torch.exp(math.log(s0) + 0.3 * torch.randn(P, 3, generator=g))
+    if kind != "shell":
+        scales = torch.exp(math.log(s0) + 0.3 * torch.randn(P, 3, generator=g))
     q = torch.randn(P, 4, generator=g)
     rotations = q / q.norm(dim=1, keepdim=True)
     opacities = torch.sigmoid(2.0 * torch.randn(P, 1, generator=g))

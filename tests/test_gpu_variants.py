@@ -406,3 +406,29 @@ def test_list_segments_at_their_boundaries(hip_device, shape, opacity, n):
         scale = float(np.abs(a).max())
         assert scale > 0 and float(np.abs(a - b).max()) <= 4e-6 * scale, (k, float(np.abs(a - b).max()) / scale)
     hp.compare_grads(segs["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+def test_pixel_sized_gaussians_in_one_layer_against_the_oracle(hip_device):
+    """LucidDreamer's own scene statistics (synthetic.make_cloud kind "shell": one layer of pixel-sized isotropic Gaussians lifted
+    from a panorama, bench.py workload ld512) at a tenth of the size: lists of ~300 per tile of splats a few pixels wide --
+    image, depth, radii and gradients against the oracle; segments on and off agree."""
+    cloud = synthetic.make_cloud(100_000, "shell", 0)
+    W = H = 162
+    cam = cameras.rotate360_path(W, H, n_views=30)[3]
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.1, 0.1, 0.1])
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    outs = []
+    try:
+        for seg in (1, 0):
+            _lib.tune_set("bwd_seg", seg)
+            outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
+    finally:
+        _lib.tune_set("bwd_seg", -1)
+    a, b = outs
+    assert int((ref["radii"] > 0).sum()) > 10_000
+    hp.compare_forward(a, ref, max_fragile=max(8, 1e-3 * W * H))
+    hp.compare_grads_by_row(a, ref, 100_000)
+    for k in a["grads"]:
+        scale = float(np.abs(b["grads"][k]).max())
+        assert float(np.abs(a["grads"][k] - b["grads"][k]).max()) <= 4e-6 * scale, k

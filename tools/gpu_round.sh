@@ -10,7 +10,7 @@ mkdir -p $R/gpurun_out
 cd $R
 python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_c3.json 2> gpurun_out/${TAG}_bench_c3.err
 tail -c 300 gpurun_out/${TAG}_bench_c3.err
-for wl in c2 c3box c4shape c5shape; do
+for wl in c2 c3box c4shape c5shape ld512; do
   python bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_${wl}.json 2>/dev/null
 done
 # single-stream kernel statistics of the 512^2 dense shape (one view alone on the GPU: what the training loop sees)
