@@ -408,7 +408,8 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     lone = None
     if in_flight >= 2:
         lone = profiled_stages(wl, api, exact, steps, world, dev, args, 1)[0]
-    # name of the blend-backward kernel each of the two passes launched (the rule of render_bwd.hip blend_shape)
+    # name of the blend-backward kernel each of the two passes launched (the rule of render_bwd.hip blend_shape; the forward
+    # follows it: render_fwd.hip launch_render_fwd)
     bwd_tile = wl.T > 3072 and in_flight >= 2
     bwd_name = "k_render_bwd_tile" if bwd_tile else "k_render_bwd<"
     P, V_mean, R_mean, N, T, K, M, V = wl.P, wl.V_mean, wl.R_mean, wl.N, wl.T, wl.K, wl.M, wl.V
@@ -487,8 +488,9 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
             ratios = {}
             for st in single_kernel:
                 # the kernel the steady state runs: the pooled preprocess (the thread-per-Gaussian one serves the warm-up view)
+                # ... and the blend kernels of the shape the headline launched (one wave per tile at 1080p with views in flight)
                 names = sorted((k for k, v in allpmc.items() if isinstance(v, dict) and k.startswith("k_" + st)),
-                               key=lambda k: (0 if "_pool" in k else 1, k))
+                               key=lambda k: (0 if "_pool" in k else 1, 0 if ("_tile" in k) == bwd_tile else 1, k))
                 pk = allpmc[names[0]] if names else None
                 if pk and "FETCH_SIZE" in pk and "WRITE_SIZE" in pk:
                     tb = (2.0 * pk["FETCH_SIZE"] + pk["WRITE_SIZE"]) * 1024

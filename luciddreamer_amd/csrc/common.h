@@ -424,7 +424,8 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
-                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final, hipStream_t s);
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final,
+                       long long inst_hint, hipStream_t s);
 // seg_bound: upper bound of GeomHeader::n_seg known to the host (bin_seg_capacity of the instance bound of the call)
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,

@@ -2,8 +2,10 @@
 //
 // Replaces FORWARD::render / renderCUDA (RAST/cuda_rasterizer/forward.cu:261-391).  Per-pixel
 // semantics are the reference's exactly (same skip tests, same 0.99 clamp, same T < 1e-4 stop,
-// same depth normalisation).  The kernel is VALU-issue bound (measured: ~100 % VALU busy, HBM idle), so
-// the execution shape is chosen to minimise wave-instructions per pixel x Gaussian pair:
+// same depth normalisation).  Two kernels with the same results to the bit (launch_render_fwd picks): k_render_fwd below --
+// four waves per tile, what a lone view and every small image gets -- and k_render_fwd_tile further down -- one wave per tile, a
+// lane owns four pixels, for large images while other views' kernels share the GPU.  k_render_fwd is VALU-issue bound
+// (measured: 88 % VALU busy at C3, HBM idle), so its shape is chosen to minimise wave-instructions per pixel x Gaussian pair:
 //   * one 256-thread workgroup per 16x16 tile = 4 wave64; a wave owns ONE 8x8 quadrant, a lane one pixel.  (An earlier
 //     shape -- 2 waves per tile, two pixels per lane, a candidate stepping only the pixels whose quadrant it hit -- shared
 //     the candidate walk and the LDS reads between two quadrants; the quadrant-per-wave shape measured 6 % (C3) to 11 %
@@ -243,25 +245,188 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
     }
 }
 
+
+// The TILE shape of the forward: ONE wave64 per 16x16 tile, a lane owns FOUR pixels -- the same position (l & 7, l >> 3) in
+// each of the tile's four 8x8 quadrants (the layout of render_bwd.hip's TILE shape).  A round stages 64 list entries, one per
+// lane: the lane culls its own entry against the four quadrants from registers (the four outcomes leave as ONE 4-byte store
+// for the backward), the wave walks the union of the four candidate masks, reads a candidate's fields once, and steps only the
+// quadrants it hit (scalar branches on the mask bits).  What it is for: everything the 4-wave shape pays per candidate and
+// QUADRANT that is not a pixel step -- three broadcast LDS reads (8 + 6 + 6 LDS cycles), the mask bookkeeping on the scalar
+// unit, the row terms of the exponent -- is paid once per candidate and TILE (an instance reaches 2.33 of its tile's 4
+// quadrants at C3); no barriers, no partner waves to wait for, 3 KB of LDS.  Same operations per pixel and candidate in the
+// same order as the quadrant kernel: the same bits (tests/test_gpu_variants.py).
+constexpr int TSTAGE = 64;
+template <bool STRICT>
+__global__ void __launch_bounds__(64)
+k_render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
+                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
+                  const GaussRec* __restrict__ rec,
+                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
+                  float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
+                  GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,
+                  uint32_t* __restrict__ tile_seg0, float4* __restrict__ c_final)
+{
+    __shared__ float4 s_q0[TSTAGE];     // as in k_render_fwd
+    __shared__ float4 s_q1[TSTAGE];
+    __shared__ float4 s_q2[TSTAGE];
+
+    const int tile = blend_tile(tile_map, num_tiles);
+    if (tile < 0) return;
+    const int tx = tile % gx, ty = tile / gx;
+    const int l = threadIdx.x;
+    const int x0 = tx * TILE_X, y0 = ty * TILE_Y;
+    const int pxl = x0 + (l & 7), pyt = y0 + (l >> 3);                // the lane's pixel in quadrant 0; + 8 for the right / lower ones
+    const float pxf[2] = { (float)pxl, (float)(pxl + 8) }, pyf[2] = { (float)pyt, (float)(pyt + 8) };
+    const float bx[2][2] = { { (float)x0, (float)(x0 + 7) }, { (float)(x0 + 8), (float)(x0 + 15) } };
+    const float by[2][2] = { { (float)y0, (float)(y0 + 7) }, { (float)(y0 + 8), (float)(y0 + 15) } };
+
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    PixState A[4];
+    uint64_t done[4];
+    bool inside[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        A[q] = PixState{ 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u };
+        inside[q] = pxl + (q & 1) * 8 < W && pyt + (q >> 1) * 8 < H;
+        done[q] = __builtin_amdgcn_ballot_w64(!inside[q]);
+    }
+
+    // list segments for the backward: as in k_render_fwd (one atomic per tile; a checkpoint per pixel every BWD_SEG positions)
+    static_assert(BWD_SEG % TSTAGE == 0, "checkpoints fall on round boundaries");
+    const int n_seg = total > 0 ? (total - 1) / BWD_SEG : 0;
+    uint32_t seg0 = 0;
+    if (n_seg > 0) {
+        if (l == 0) { seg0 = atomicAdd(&hdr->n_seg, (uint32_t)n_seg); tile_seg0[tile] = seg0; }
+        seg0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)seg0);
+        for (int g = 1 + l; g <= n_seg; g += 64) seg_list[seg0 + g - 1] = make_uint2((uint32_t)tile, (uint32_t)g);
+    }
+
+    // A round's records arrive through three dependent loads (list -> Gaussian id -> record), and a single-wave workgroup has no
+    // partner to wait with: the first two are issued a round ahead and are in flight while this round's candidates are walked
+    // (positions beyond the list's end re-read its last entry, never staged).  Fetching the records ahead as well -- into
+    // registers: the compiler waits for them where they are issued; straight into a second set of LDS planes with
+    // global_load_lds_dwordx4: correct, 6 instead of 7 waves per SIMD -- measured no faster (profiles/r05w_ab_fwd_tile.json).
+    const uint32_t* __restrict__ plist = point_list + range.x;
+    uint32_t id_next = total > 0 ? inst_gid[plist[min(l, total - 1)]] : 0u;
+    for (int base = 0; base < total; base += TSTAGE) {
+        if ((done[0] & done[1] & done[2] & done[3]) == ~0ull) break;
+        const int cnt = min(TSTAGE, total - base);
+        const uint32_t id = id_next;
+        if (base + TSTAGE < total) id_next = inst_gid[plist[min(base + TSTAGE + l, total - 1)]];
+        if (base > 0 && base % BWD_SEG == 0) {
+            // (a quadrant whose pixels are all done stopped in front of this position: the backward starts those from final_T)
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (done[q] != ~0ull)
+                    ckpt[(size_t)(seg0 + base / BWD_SEG - 1) * TILE_PIX + q * 64 + l] = make_float4(A[q].T, A[q].Cr, A[q].Cg, A[q].Cb);
+        }
+        bool hit[4] = { false, false, false, false };
+        lds_barrier();                                                // (the previous round's reads are done: one wave, no waiting)
+        if (l < cnt) {
+            const float4* g = reinterpret_cast<const float4*>(rec + id);
+            const float4 a = g[0], b = g[1], c = g[2];
+            const float4 q0 = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            const float4 q1 = STRICT ? make_float4(b.x, b.y, c.y, c.z) : make_float4((-0.5f * LOG2E) * b.x, b.y, c.y, LOG2E * c.z);
+            s_q0[l] = q0; s_q1[l] = q1; s_q2[l] = make_float4(b.z, b.w, c.x, 0.f);
+            const float r_c = -a.w / b.x, r_a = -a.w / a.z;
+            const float ca = STRICT ? q0.z : -2.0f * q0.z, cb = STRICT ? q0.w : -q0.w, cc = STRICT ? q1.x : -2.0f * q1.x;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                hit[q] = box_hit(q0.x, q0.y, ca, cb, cc, r_c, r_a, q1.w, bx[q & 1][0], bx[q & 1][1], by[q >> 1][0], by[q >> 1][1]);
+            // the outcome per quadrant, kept for the backward (common.h BinLayout::quad_hits)
+            reinterpret_cast<uint32_t*>(quad_hits)[(size_t)range.x + (size_t)(base + l)] =
+                (hit[0] ? 1u : 0u) | (hit[1] ? 0x100u : 0u) | (hit[2] ? 0x10000u : 0u) | (hit[3] ? 0x1000000u : 0u);
+        }
+        uint64_t m[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) m[q] = done[q] == ~0ull ? 0ull : __ballot(hit[q]);
+        uint64_t mask = (m[0] | m[1]) | (m[2] | m[3]);
+        lds_barrier();
+        while (mask) {
+            const int k = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const float4 fa = s_q0[k];
+            const float4 fb = s_q1[k];
+            const float4 fc = s_q2[k];
+            const uint32_t pos0 = (uint32_t)(base + k);
+            const uint64_t bit = 1ull << k;
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+                if (((m[2 * row] | m[2 * row + 1]) & bit) == 0ull) continue;
+                float r0, r1;
+                gauss_row<STRICT>(fa.w, fb.x, fa.y - pyf[row], r0, r1);                         // common.h gauss_power
+#pragma unroll
+                for (int col = 0; col < 2; col++) {
+                    const int q = 2 * row + col;
+                    if ((m[q] & bit) == 0ull) continue;
+                    fwd_pixel<STRICT>(A[q], done[q], fa.z, fa.w, fb.x, r0, r1, fa.x - pxf[col], fb.y, fc.x, fc.y, fc.z, fb.z, pos0);
+                    if (done[q] == ~0ull) {                            // the quadrant is finished: its later candidates are nobody's
+                        m[q] = 0ull;
+                        mask &= (m[0] | m[1]) | (m[2] | m[3]);
+                    }
+                }
+            }
+        }
+    }
+
+    const size_t N = (size_t)W * H;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        if (!inside[q]) continue;
+        const int px = pxl + (q & 1) * 8, py = pyt + (q >> 1) * 8;
+        const size_t pix = (size_t)py * W + px;
+        final_T[pix] = A[q].T;
+        n_contrib[pix] = __builtin_amdgcn_inverse_ballot_w64(done[q]) ? A[q].last : (uint32_t)total;
+        const float fr = A[q].Cr + A[q].T * bg[0], fg = A[q].Cg + A[q].T * bg[1], fb = A[q].Cb + A[q].T * bg[2];
+        out_color[pix] = fr;
+        out_color[N + pix] = fg;
+        out_color[2 * N + pix] = fb;
+        if (n_seg > 0) c_final[pix] = make_float4(fr, fg, fb, 0.f);
+        out_depth[pix] = (A[q].acc > 0.5f) ? A[q].D / A[q].acc : 0.0f;         // forward.cu:384-388
+    }
+}
+
 }  // namespace
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
-                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final, hipStream_t s)
+                       GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final,
+                       long long inst_hint, hipStream_t s)
 {
     const int num_tiles = gx * gy;
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    // lr_tune_set("fwd_pair", 0 / 1) forces the candidate loop (A/B runs); default: pairs where the image has few tiles
-    const bool pair = tune_get(TUNE_FWD_PAIR) >= 0 ? tune_get(TUNE_FWD_PAIR) != 0 : num_tiles <= 3072;
+    // Shape (same images, depth, checkpoints and gradients to the bit from all three):
+    //   quadrant kernel (4 waves per tile) -- small images, and a lone large view: 52 us at C3 against the tile kernel's 64;
+    //   ... with candidate pairs -- images of <= 3072 tiles (lists of PAIR_MIN_LIST and more);
+    //   tile kernel (1 wave per tile) -- large images while other views' kernels are in flight: 10 % fewer VALU instructions and
+    //   59 % fewer LDS reads per C3 view (28.7 M -> 25.7 M, 3.10 M -> 1.26 M; profiles/r05x_pmc_fwdtile_*.json) but only 3.4 of its
+    //   7 waves per SIMD resident on average when it has the GPU to itself.  Three views in flight, quadrant -> tile kernel
+    //   (profiles/r05u_ab_fwd_tile.json, r05v_, r05w_: three boxes): C3 +1.8 ... +3.2 % views/s, C2 +2.1 ... +3.6 %,
+    //   3 M / 1440p (700 instances per tile) -0 ... +1 %, dense 1 M cloud at 1080p (460 per tile) -2 ... -3 %.  So: the rule of
+    //   the backward's shapes (render_bwd.hip blend_shape), and not on scenes whose earlier views told the host that the lists
+    //   are longer than a staging round of the quadrant kernel on average (inst_hint: api.hip view_hint_instances; -1 = unknown).
+    // lr_tune_set("fwd_pair", 0 / 1 / 2) forces quadrant / quadrant with pairs / tile (A/B runs).
+    const int knob = tune_get(TUNE_FWD_PAIR);
+    const bool long_lists = inst_hint > (long long)BATCH * num_tiles;
+    const bool tile_shape = knob >= 0 ? knob == 2 : (num_tiles > 3072 && views_in_flight() >= 2 && !long_lists);
+    const bool pair = knob >= 0 ? knob == 1 : num_tiles <= 3072;
     const bool strict = tune_get(TUNE_STRICT) > 0;
-#define LR_FWD(S, PR) hipLaunchKernelGGL((k_render_fwd<S, PR>), dim3(grid), dim3(THREADS), 0, s, W, H, gx, num_tiles, tile_map, ranges, \
-                                         point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, quad_hits, hdr,   \
-                                         seg_list, ckpt, tile_seg0, c_final)
+#define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
+                    quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
+    if (tile_shape) {
+        if (strict) hipLaunchKernelGGL((k_render_fwd_tile<true>), dim3(grid), dim3(64), 0, s, LR_FWD_ARGS);
+        else hipLaunchKernelGGL((k_render_fwd_tile<false>), dim3(grid), dim3(64), 0, s, LR_FWD_ARGS);
+        return;
+    }
+#define LR_FWD(S, PR) hipLaunchKernelGGL((k_render_fwd<S, PR>), dim3(grid), dim3(THREADS), 0, s, LR_FWD_ARGS)
     if (strict) { if (pair) LR_FWD(true, true); else LR_FWD(true, false); }
     else { if (pair) LR_FWD(false, true); else LR_FWD(false, false); }
+#undef LR_FWD_ARGS
 #undef LR_FWD
 }
 

@@ -336,22 +336,25 @@ def test_list_segments_give_the_gradients_of_the_whole_list(hip_device, shape, P
 @pytest.mark.parametrize("P,W,H,scale_mult", [(60_000, 640, 360, 1.0), (40_000, 320, 208, 5.0), (20_000, 1280, 720, 2.0)])
 def test_forward_candidate_pairs_give_the_same_bits(hip_device, P, W, H, scale_mult):
     """Small images take the blend forward's candidates two at a time (render_fwd.hip PAIR: both alphas side by side, then the
-    two steps of the T recursion in order); lr_tune_set("fwd_pair", 0 / 1) forces either loop.  Same operations per pixel and
-    candidate in the same order: images, depth, n_contrib (through the gradients) and checkpoints are the same bits."""
+    two steps of the T recursion in order); large images with other views in flight take the one-wave-per-tile kernel (a lane owns
+    four pixels, a candidate's fields are read once per tile); lr_tune_set("fwd_pair", 0 / 1 / 2) forces quadrant / pairs / tile.
+    Same operations per pixel and candidate in the same order: images, depth, n_contrib (through the gradients) and checkpoints
+    are the same bits."""
     cam, cloud = hp.box_setup(P, W, H, seed=21, scale_mult=scale_mult)
     g = synthetic.upstream_grad(H, W)
     bg = torch.tensor([0.3, 0.1, 0.2])
     outs = []
     try:
-        for v in (0, 1):
+        for v in (0, 1, 2):
             _lib.tune_set("fwd_pair", v)
             outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
     finally:
         _lib.tune_set("fwd_pair", -1)
-    a, b = outs
-    assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"])
-    for k in a["grads"]:
-        assert np.array_equal(a["grads"][k], b["grads"][k]), k
+    a = outs[0]
+    for v, b in zip((1, 2), outs[1:]):
+        assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"]), v
+        for k in a["grads"]:
+            assert np.array_equal(a["grads"][k], b["grads"][k]), (v, k)
 
 
 def _stack_cloud(n, W, H, cam, px, py, opacity, seed):
@@ -406,6 +409,38 @@ def test_list_segments_at_their_boundaries(hip_device, shape, opacity, n):
         scale = float(np.abs(a).max())
         assert scale > 0 and float(np.abs(a - b).max()) <= 4e-6 * scale, (k, float(np.abs(a - b).max()) / scale)
     hp.compare_grads(segs["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+@pytest.mark.parametrize("n,opacity,W,H", [(257, 0.006, 64, 48), (513, 0.08, 64, 48), (700, 0.006, 70, 41), (1100, 0.02, 70, 41)])
+def test_tile_forward_with_segments_and_ragged_image(hip_device, strict, n, opacity, W, H):
+    """The one-wave-per-tile forward (render_fwd.hip k_render_fwd_tile: 64 list entries per round, a checkpoint every 256) on
+    lists that cross segment boundaries, on an image whose last tile column and row are cut (70 x 41: quadrants partly and wholly
+    outside), in both arithmetic modes: the quadrant kernel's bits -- image, depth, every gradient through every backward shape --
+    and the oracle's values."""
+    cam = cameras.identity_camera(W, H)
+    cloud = _stack_cloud(n, W, H, cam, W - 9.0, H - 5.0, opacity, seed=n + 1)
+    g = synthetic.upstream_grad(H, W)
+    bg = torch.tensor([0.2, 0.4, 0.1])
+    _lib.tune_set("strict", strict)
+    try:
+        for shape in (0, 1, 2):
+            _lib.tune_set("blend_quad", shape)
+            outs = []
+            for v in (0, 2):
+                _lib.tune_set("fwd_pair", v)
+                outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
+            a, b = outs
+            assert np.array_equal(a["color"], b["color"]) and np.array_equal(a["depth"], b["depth"]), shape
+            for k in a["grads"]:
+                assert np.array_equal(a["grads"][k], b["grads"][k]), (shape, k)
+    finally:
+        _lib.tune_set("fwd_pair", -1)
+        _lib.tune_set("blend_quad", -1)
+        _lib.tune_set("strict", -1)
+    ref = hp.run_oracle(cloud, cam, 3, bg, g)
+    hp.compare_forward(b, ref)
+    hp.compare_grads(b["grads"], ref["grads"], names=["means2D", "opacity", "means3D", "sh", "scales", "rotations"])
 
 
 def test_pixel_sized_gaussians_in_one_layer_against_the_oracle(hip_device):
