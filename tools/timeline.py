@@ -90,3 +90,20 @@ for kid, s, e, *q in seg:
 print("  kernel: launches, mean us, mean gap after the previous kernel of the same queue")
 for k, a in sorted(per.items(), key=lambda kv: -kv[1][0]):
     print(f"    {k:28s} {a[1]:5d}  {a[0] / a[1]:7.1f}  {a[2] / max(a[3], 1):6.1f}")
+
+# the gaps in front of a view's first kernel (the preprocess), per queue: where a stream waited between two views -- the host
+# behind, or the step boundary (the streams are forked from and joined to the caller's stream once per step)
+gaps, prev_end, queues = [], {}, set()
+for kid, s, e, *q in seg:
+    key = q[0] if q else 0
+    if "k_preprocess" in names.get(kid, ""):
+        queues.add(key)
+        if key in prev_end:
+            gaps.append(max(0.0, (s - prev_end[key]) / 1e3))
+    prev_end[key] = e
+if gaps:
+    gaps.sort()
+    big_g = [g for g in gaps if g > 100.0]
+    print(f"  gap in front of a view's first kernel: {len(gaps)} views on {len(queues)} queues, median {gaps[len(gaps) // 2]:.1f} us, "
+          f"mean {sum(gaps) / len(gaps):.1f} us; the {len(big_g)} gaps above 100 us (mean {sum(big_g) / max(len(big_g), 1):.0f} us) are "
+          f"{100 * sum(big_g) / (max(len(queues), 1) * wall):.1f} % of every queue's wall time, all the others {100 * (sum(gaps) - sum(big_g)) / (max(len(queues), 1) * wall):.1f} %")
