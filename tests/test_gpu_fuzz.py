@@ -46,6 +46,29 @@ def test_random_scene_matches_oracle(hip_device, seed):
         hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
 
 
+@pytest.mark.parametrize("seed", range(24, 36))
+def test_random_scene_through_the_tile_kernels_matches_oracle(hip_device, seed):
+    """The same kind of scene through the kernels large images get while other views are in flight -- blend forward and backward
+    one wave per tile (lr_tune_set("fwd_pair", 2), ("blend_quad", 2)) -- against the oracle, and bit for bit against the default
+    kernels' image."""
+    from luciddreamer_amd import _lib
+    cloud, cam, degree, bg, mod, (W, H) = _scene(seed)
+    g = synthetic.upstream_grad(H, W, seed=seed)
+    ref = hp.run_oracle(cloud, cam, degree, bg, grad_color=g, scale_modifier=mod)
+    plain = hp.run_hip(cloud, cam, degree, bg, hip_device, grad_color=g, scale_modifier=mod)
+    try:
+        _lib.tune_set("fwd_pair", 2)
+        _lib.tune_set("blend_quad", 2)
+        hip = hp.run_hip(cloud, cam, degree, bg, hip_device, grad_color=g, scale_modifier=mod)
+    finally:
+        _lib.tune_set("fwd_pair", -1)
+        _lib.tune_set("blend_quad", -1)
+    assert np.array_equal(plain["color"], hip["color"]) and np.array_equal(plain["depth"], hip["depth"])
+    hp.compare_forward(hip, ref, max_fragile=16)
+    if not ref["res"].stage()["fragile"].any():
+        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scene_raw_path_matches_activated(hip_device, seed):
     from luciddreamer_amd.gaussian_renderer import GaussianCloud, render, render_raw
