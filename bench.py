@@ -860,6 +860,29 @@ def main():
                     "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
+        # the figures beside the headline that a reader of the driver's record needs (the driver keeps `config` whole):
+        # the same step in strict mode, the API LucidDreamer calls, the >= 1 s repeat of the headline step, LucidDreamer's own
+        # loop after install(), and whether the headline's own kernels met the oracle at this size
+        c5 = (cpu_baseline or {}).get("c5_train_loop") or {}
+        hs = (parity or {}).get("headline_step") if isinstance(parity, dict) else None
+        cfg.update({
+            "strict_mode_views_per_s": (entry_points or {}).get("strict_mode_views_per_s"),
+            "drop_in_views_per_s": (entry_points or {}).get("drop_in_views_per_s"),
+            "drop_in_host_issue_ms_per_step": (entry_points or {}).get("drop_in_host_issue_ms_per_step"),
+            "sustained_views_per_s": (sustained or {}).get("views_per_s"),
+            "c5_train_loop_ms_per_iter": {k: (c5.get(k) or {}).get("ms_per_iter") for k in
+                                          ("this_rasterizer", "this_rasterizer_after_install", "with_optional_pieces",
+                                           "reference_kernels_on_this_gpu")} if c5 and "error" not in c5 else c5.get("error"),
+            "headline_step_parity": None if not hs else {
+                m: {"kernel_shapes": hs[m]["kernel_shapes"], "grad_rows_above_1e-4_worst_tensor": hs[m]["grad_rows_above_1e-4_worst_tensor"],
+                    "worst_grad_row_rel": hs[m]["worst_grad_row_rel"],
+                    "every_row_above_1e-4_touches_a_flagged_pixel": hs[m]["every_row_above_1e-4_touches_a_flagged_pixel"]}
+                for m in ("default", "strict")},
+            "headline_kernels_image_parity": None if not isinstance(parity, dict) or "per_view" not in parity else {
+                "max_abs_rgb_err": max(v["headline_kernels"]["max_abs_rgb_err"] for v in parity["per_view"]),
+                "pixels_above_1e-5_unmasked": max(v["headline_kernels"]["pixels_above_1e-5_unmasked"] for v in parity["per_view"]),
+                "kernel_shapes": parity["per_view"][0]["headline_kernels"]["kernel_shapes"]},
+        })
         line = {
             "metric": metric,
             "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -883,23 +906,52 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def _hip_one_view(wl, cam_index=0):
+def _hip_one_view(wl, cam_index=0, views_in_flight=1):
     """One view of the workload through the drop-in operator in exact mode, with its own leaves (dense gradients of that
-    view alone): what `parity` compares with the oracle.  Outside every timed region."""
-    from luciddreamer_amd import config
+    view alone): what `parity` compares with the oracle.  Outside every timed region.  views_in_flight >= 2: the hint the
+    multi-stream entry points give the library, so that the kernels of the HEADLINE run (k_render_fwd_tile / k_render_bwd_tile at
+    1080p) and not the lone-view shapes; the shapes that ran are returned."""
+    from luciddreamer_amd import _lib, config
     config.reset()
     config.set_async(False)
     config.set_fused_grad_accumulation(False)
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in wl.leaf.items()}
     means2D = torch.zeros(wl.P, 3, device=wl.dev, requires_grad=True)
-    color, radii, depth = wl.rasterizers[cam_index](means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
-                                                     shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
-    color.backward(wl.grad_color)
-    torch.cuda.synchronize()
+    _lib.tune_set("views_in_flight", views_in_flight if views_in_flight >= 2 else -1)
+    try:
+        color, radii, depth = wl.rasterizers[cam_index](means3D=leaf["means3D"], means2D=means2D, opacities=leaf["opacities"],
+                                                         shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+        color.backward(wl.grad_color)
+        torch.cuda.synchronize()
+        shapes = _lib.last_launch_shapes()
+    finally:
+        _lib.tune_set("views_in_flight", -1)
     g = lambda t: t.grad.detach().cpu().numpy()
     return {"color": color.detach().cpu().numpy(), "depth": depth.detach().cpu().numpy(), "radii": radii.cpu().numpy(),
+            "kernel_shapes": {"forward": shapes[0], "backward": shapes[1]},
             "grads": {"means2D": g(means2D), "opacity": g(leaf["opacities"]), "means3D": g(leaf["means3D"]),
                       "sh": g(leaf["shs"]), "scales": g(leaf["scales"]), "rotations": g(leaf["rotations"])}}
+
+
+def _hip_headline_step(wl, view_ids, n_streams=3):
+    """The HEADLINE's own entry point and kernels on a few views: ONE lr_views_accumulate call (parallel.ViewBatch, async mode,
+    `n_streams` views in flight -- at 1080p k_render_fwd_tile + k_render_bwd_tile) accumulating the views' gradients into
+    zeroed tensors.  Returns the accumulated gradients (numpy) and the kernel shapes that ran.  Outside every timed region."""
+    from luciddreamer_amd import _lib, config, parallel
+    config.reset()
+    config.set_async(True)
+    cams = [wl.cams[i] for i in view_ids]
+    batch = parallel.ViewBatch(cams, [wl.grad_color] * len(cams), wl.degree, wl.bg, wl.capacity, n_streams=n_streams)
+    leaf = wl.leaf
+    acc = {"means3D": torch.zeros_like(leaf["means3D"]), "means2D": torch.zeros(wl.P, 3, device=wl.dev),
+           "opacity": torch.zeros_like(leaf["opacities"]), "sh": torch.zeros_like(leaf["shs"]),
+           "scales": torch.zeros_like(leaf["scales"]), "rotations": torch.zeros_like(leaf["rotations"])}
+    with torch.no_grad():
+        batch.run(leaf["means3D"].detach(), leaf["opacities"].detach(), leaf["scales"].detach(), leaf["rotations"].detach(),
+                  leaf["shs"].detach(), acc)
+    batch.check()                                   # synchronises; raises if a view overflowed its binning capacity
+    shapes = _lib.last_launch_shapes()
+    return {k: v.cpu().numpy() for k, v in acc.items()}, {"forward": shapes[0], "backward": shapes[1]}
 
 
 def run_cpu_baseline(wl):
@@ -1094,7 +1146,19 @@ def run_cpu_baseline(wl):
     try:
         names = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")
         per_view = []
-        for vi in [i for i in (0, 11, 19) if i < len(cams)] or [0]:
+        view_ids = [i for i in (0, 11, 19) if i < len(cams)] or [0]
+        oracle_sum = {}                 # sum over the views of the oracle's gradients (float64): what the headline's step accumulates
+        touch_info = []                 # per view: what decides whether a row beyond 1e-4 sits on an oracle-flagged pixel
+
+        def touches_flagged(i, st, fx, fy):
+            """Row i belongs to a splat whose own alpha reaches the 1/255 threshold (to within 10 %) on a pixel the oracle
+            flags as sitting within float32 rounding of a discrete decision."""
+            ca, cb, cc, op = st["conic_opacity"][i].astype(np.float64)
+            dx, dy = st["means2D"][i, 0] - fx.astype(np.float64), st["means2D"][i, 1] - fy.astype(np.float64)
+            power = -0.5 * (ca * dx * dx + cc * dy * dy) - cb * dx * dy
+            return bool(((power <= 1e-6) & (op * np.exp(np.minimum(power, 0.0)) >= 0.9 / 255.0)).any())
+
+        for vi in view_ids:
             _, _, res, grads = one_view(oracle, cams[vi], keep=True)
             hip = _hip_one_view(wl, vi)
             st = res.stage()
@@ -1104,6 +1168,10 @@ def run_cpu_baseline(wl):
             cerr = np.abs(hip["color"] - res.color)
             derr = np.abs(hip["depth"][0] - res.depth[0]) / np.maximum(1.0, np.abs(res.depth[0]))
             ref_g = dict(zip(names, grads[:8]))
+            for k in hip["grads"]:
+                b64 = ref_g[k].reshape(hip["grads"][k].shape).astype(np.float64)
+                oracle_sum[k] = b64 if k not in oracle_sum else oracle_sum[k] + b64
+            touch_info.append({"conic_opacity": st["conic_opacity"].copy(), "means2D": st["means2D"].copy(), "fx": fx, "fy": fy})
             gerr, all_touch = {}, True
             for k, a in hip["grads"].items():
                 b = ref_g[k].reshape(a.shape)
@@ -1113,11 +1181,29 @@ def run_cpu_baseline(wl):
                 # a row beyond the tolerance must belong to a splat whose own alpha reaches the 1/255 threshold (to within
                 # 10 %) on a pixel the oracle flags as sitting within float32 rounding of a discrete decision
                 for i in bad:
-                    ca, cb, cc, op = st["conic_opacity"][i].astype(np.float64)
-                    dx, dy = st["means2D"][i, 0] - fx.astype(np.float64), st["means2D"][i, 1] - fy.astype(np.float64)
-                    power = -0.5 * (ca * dx * dx + cc * dy * dy) - cb * dx * dy
-                    all_touch &= bool(((power <= 1e-6) & (op * np.exp(np.minimum(power, 0.0)) >= 0.9 / 255.0)).any())
+                    all_touch &= touches_flagged(i, st, fx, fy)
                 gerr[k] = {"max_rel": float(row.max() / scale) if scale > 0 else float(row.max()), "rows_above_1e-4": int(len(bad))}
+            # the same view through the kernels the HEADLINE launches (three views in flight: at 1080p the one-wave-per-tile pair)
+            ht = _hip_one_view(wl, vi, views_in_flight=3)
+            t_cerr = np.abs(ht["color"] - res.color)
+            t_rows, t_worst, t_touch = 0, 0.0, True
+            for k, a in ht["grads"].items():
+                b = ref_g[k].reshape(a.shape)
+                scale = float(np.abs(b).max())
+                row = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1)
+                bad = np.nonzero(row > 1e-4 * scale)[0]
+                t_rows = max(t_rows, int(len(bad)))
+                t_worst = max(t_worst, float(row.max() / scale) if scale > 0 else 0.0)
+                for i in bad:
+                    t_touch &= touches_flagged(i, st, fx, fy)
+            headline_kernels_view = {
+                "kernel_shapes": ht["kernel_shapes"], "max_abs_rgb_err": float(t_cerr[:, ~fc].max()),
+                "pixels_above_1e-5_unmasked": int((t_cerr.max(axis=0) > 1e-5).sum()),
+                "same_bits_as_lone_view_kernels": bool(np.array_equal(ht["color"], hip["color"]) and np.array_equal(ht["depth"], hip["depth"])),
+                "radii_exact": bool(np.array_equal(ht["radii"], res.radii)),
+                "grad_rows_above_1e-4_worst_tensor": t_rows, "worst_grad_row_rel": t_worst,
+                "every_row_above_1e-4_touches_a_flagged_pixel": t_touch}
+            del ht
             # the same view in STRICT mode (config.set_strict_parity: the reference's own float operations): nothing masked
             from luciddreamer_amd import config as _cfg
             _cfg.set_strict_parity(True)
@@ -1138,12 +1224,40 @@ def run_cpu_baseline(wl):
                            "radii_exact": bool(np.array_equal(hs["radii"], res.radii))}
             del hs
             per_view.append({
-                "view": vi, "strict_mode": strict_view, "max_abs_rgb_err": float(cerr[:, ~fc].max()), "max_abs_rgb_err_unmasked": float(cerr.max()),
+                "view": vi, "strict_mode": strict_view, "headline_kernels": headline_kernels_view, "max_abs_rgb_err": float(cerr[:, ~fc].max()), "max_abs_rgb_err_unmasked": float(cerr.max()),
                 "max_abs_depth_rel_err": float(derr[~(fc | fd)].max()), "max_abs_depth_rel_err_unmasked": float(derr.max()),
                 "threshold_pixels_flagged_by_oracle": int(fc.sum()), "pixels_above_1e-5_unmasked": int((cerr.max(axis=0) > 1e-5).sum()),
                 "radii_exact": bool(np.array_equal(hip["radii"], res.radii)), "grad_err_vs_tensor_max": gerr,
                 "every_row_above_1e-4_touches_a_flagged_pixel": all_touch})
             del res, grads, hip
+        # ---- the headline's own entry point: one lr_views_accumulate call over the same views, three in flight, against the
+        # SUM of the oracle's backwards (backward.cu:399-586 per view; gradients are additive over views), default and strict
+        headline_step = {}
+        for mode in ("default", "strict"):
+            from luciddreamer_amd import config as _cfg
+            _cfg.set_strict_parity(mode == "strict")
+            try:
+                got, shapes = _hip_headline_step(wl, view_ids, n_streams=3)
+            finally:
+                _cfg.set_strict_parity(False)
+            rows_worst, rel_worst, touch, per_tensor = 0, 0.0, True, {}
+            for k, a in got.items():
+                b = oracle_sum[k].reshape(a.shape)
+                scale = float(np.abs(b).max())
+                row = np.abs(a.astype(np.float64) - b).reshape(a.shape[0], -1).max(axis=1)
+                bad = np.nonzero(row > 1e-4 * scale)[0]
+                for i in bad:
+                    touch &= any(touches_flagged(i, t, t["fx"], t["fy"]) for t in touch_info)
+                per_tensor[k] = {"max_rel": float(row.max() / scale) if scale > 0 else float(row.max()), "rows_above_1e-4": int(len(bad))}
+                rows_worst, rel_worst = max(rows_worst, int(len(bad))), max(rel_worst, per_tensor[k]["max_rel"])
+            headline_step[mode] = {"kernel_shapes": shapes, "grad_err_vs_summed_oracle": per_tensor,
+                                   "grad_rows_above_1e-4_worst_tensor": rows_worst, "worst_grad_row_rel": rel_worst,
+                                   "every_row_above_1e-4_touches_a_flagged_pixel": touch}
+            del got
+        headline_step["what"] = (f"ONE lr_views_accumulate call over views {view_ids} with 3 views in flight (the headline's entry point "
+                                 "and kernels) vs the sum of the CPU oracle's per-view backwards; images of the same kernels: "
+                                 "per_view[].headline_kernels")
+        del oracle_sum, touch_info
         worst = lambda key: max(v[key] for v in per_view)
         parity = {
             "views": [v["view"] for v in per_view], "what": "drop-in operator (exact mode) vs the CPU oracle; worst over the views",
@@ -1158,6 +1272,7 @@ def run_cpu_baseline(wl):
                                        for k in per_view[0]["grad_err_vs_tensor_max"]},
             "every_row_above_1e-4_touches_a_flagged_pixel": all(v["every_row_above_1e-4_touches_a_flagged_pixel"] for v in per_view),
             "tolerance": {"rgb": 1e-5, "depth_rel": 1e-5, "grad_rel": 1e-4}, "per_view": per_view,
+            "headline_step": headline_step,
             # strict mode (entry_points.strict_mode_views_per_s is its throughput): worst over the views, NOTHING masked or exempt
             "strict_mode": {"max_abs_rgb_err_unmasked": max(v["strict_mode"]["max_abs_rgb_err_unmasked"] for v in per_view),
                             "pixels_above_1e-5_unmasked": max(v["strict_mode"]["pixels_above_1e-5_unmasked"] for v in per_view),

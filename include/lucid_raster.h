@@ -119,7 +119,11 @@ int lr_forward(lr_alloc_fn geom_alloc, void* geom_user,
  * (exact mode: R >= 0, capacity 0; async mode: R = LR_NUM_RENDERED_ON_DEVICE, capacity > 0; no host
  * synchronisation happens in either mode -- use lr_check to learn about an overflow).  As in the reference, whose backward lays the
  * binning state out from R (rasterizer_impl.cu:364-366), these two values ARE used: they bound the number of list segments the
- * blend backward launches workgroups for (one per 256 instances of a tile's list beyond its first 256).
+ * blend backward launches workgroups for (one per 256 instances of a tile's list beyond its first 256).  (Library versions up
+ * to 0.3 accepted and ignored them.)  A call whose values are SMALLER than its forward's may leave listed segments without a
+ * workgroup: the kernel notices, the view's gradients are incomplete, and the condition is reported as LR_ERR_INVALID_ARG by
+ * lr_check on the view's geom buffer and, with debug != 0, by lr_backward itself.  Larger values only cost idle workgroups;
+ * R = LR_NUM_RENDERED_ON_DEVICE with capacity 0 ("unknown") selects kernels that are correct for any launch size.
  * dL_depths is accepted and ignored, exactly as the reference does
  * (RAST/cuda_rasterizer/backward.cu:457-464, 539-554 are commented out).
  * accumulate_mask: bit k set (LR_ACC_*) => that output is ACCUMULATED into (rows of visible Gaussians are
@@ -413,7 +417,25 @@ int lr_step_abort(void);
  * accumulations while the blend backward of one view still overlaps the per-Gaussian backward of the previous one
  * (csrc/torch_ext.cpp does this for the autograd operator; lr_views_accumulate does it internally). */
 void lr_backward_wait_event(void* event);
+/* Test hook: force one of the SHIPPED code paths that the library otherwise picks by rule (value -1 = the rule again).
+ * Results never depend on it beyond float rounding between kernel shapes; the parity suite runs every path through it.
+ *   "strict" 1           the blend in the reference's own float operations (luciddreamer_amd.config.set_strict_parity)
+ *   "views_in_flight" n  hint: the caller keeps n views' kernels in flight on different streams (parallel.ViewStreams)
+ *   "blend_quad" 0/1/2   blend backward: 2 waves per tile / 4 waves per tile / 1 wave per tile
+ *   "fwd_pair" 0/1/2     blend forward: quadrant kernel / with candidate pairs / 1 wave per tile
+ *   "tile_map" 0/1       tile -> workgroup map: XCD bands / plain
+ *   "bwd_seg" 0          the blend backward walks whole lists instead of 256-position segments
+ *   "bwd_red" 4          every wave of the blend backward takes the loop copy with the `pos < last` test
+ *   "preprocess" 0/1     plain / pooled preprocess kernel;  "hit_mask" 0: no tile masks;  "tsort" 0/1/2, "walk_own" n: binning
+ *   "gauss_bwd" 0        no interleaved step accumulator
+ * Values that select a RETIRED kernel ("part_scan", "bwd_red" 0 / 3) and every LR_* environment override exist only in the
+ * diagnostics build (-DLR_DIAGNOSTICS, `python -m luciddreamer_amd.build --diagnostics`; lr_version() then says "+diagnostics");
+ * the product library rejects them with LR_ERR_INVALID_ARG and reads no environment variable. */
 int lr_tune_set(const char* name, int value);
+/* Kernel shapes of the process's last blend launches (either pointer may be NULL): forward 0 quadrant kernel, 1 with
+ * candidate pairs, 2 one wave per tile; backward 0 two waves per tile, 1 four, 2 one; -1 = none yet.  For tests that must
+ * know WHICH kernels a configuration ran (e.g. that the headline's step ran the one-wave-per-tile pair). */
+int lr_last_launch_shapes(int* forward_shape, int* backward_shape);
 int lr_profile_enable(int on);
 const char* lr_profile_stage_name(int stage);
 int lr_profile_read(double* ms_per_stage, long long* calls_per_stage, int n_stages);

@@ -9,8 +9,10 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# one library instance per process: the compiled binding (_C_ext) is linked against this very file ($ORIGIN/lib)
-LIB_PATH = os.path.join(_HERE, "lib", "liblucid_raster.so")
+# one library instance per process: the compiled binding (_C_ext) is linked against this very file ($ORIGIN/lib).
+# LR_LIB_DIR (with LD_LIBRARY_PATH pointing at the same directory, so that _C_ext resolves to the same file) switches the
+# process to another build of it -- the diagnostics build of tools/ab_bench.py (tools/diag_env.sh sets both).
+LIB_PATH = os.path.join(os.environ.get("LR_LIB_DIR") or os.path.join(_HERE, "lib"), "liblucid_raster.so")
 
 ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)
 
@@ -26,7 +28,7 @@ _lock = threading.Lock()
 
 EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_binning_bytes", "lr_forward",
            "lr_backward", "lr_forward_raw", "lr_backward_raw", "lr_mark_visible", "lr_check", "lr_dist2_workspace_bytes", "lr_dist2",
-           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read", "lr_tune_set", "lr_request_early_header",
+           "lr_profile_enable", "lr_profile_stage_name", "lr_profile_read", "lr_tune_set", "lr_last_launch_shapes", "lr_request_early_header",
            "lr_take_early_ticket", "lr_forward_ticket", "lr_backward_wait_event", "lr_step_begin", "lr_step_end", "lr_step_abort",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward", "lr_l1_dssim_backward_weights",
@@ -143,6 +145,8 @@ def lib():
         L.lr_forward_ticket.argtypes = []
         L.lr_tune_set.restype = ci
         L.lr_tune_set.argtypes = [ctypes.c_char_p, ci]
+        L.lr_last_launch_shapes.restype = ci
+        L.lr_last_launch_shapes.argtypes = [ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.lr_profile_enable.restype = ci
         L.lr_profile_enable.argtypes = [ci]
         L.lr_profile_stage_name.restype = ctypes.c_char_p
@@ -154,10 +158,27 @@ def lib():
 
 
 def tune_set(name, value):
-    """Diagnostics: switch a kernel variant at run time (lr_tune_set); value -1 restores the library's own rule."""
+    """Test hook: force one of the shipped code paths (lr_tune_set); value -1 restores the library's own rule.  Values that
+    select a retired kernel raise unless the diagnostics build is loaded (diagnostics_build())."""
     rc = lib().lr_tune_set(name.encode(), int(value))
     if rc < 0:
         raise RuntimeError(last_error())
+
+
+def diagnostics_build():
+    """True when the loaded library was compiled with -DLR_DIAGNOSTICS (retired kernels, LR_* environment overrides)."""
+    return b"+diagnostics" in lib().lr_version()
+
+
+FWD_SHAPES = {-1: None, 0: "quadrant", 1: "quadrant-pairs", 2: "tile"}
+BWD_SHAPES = {-1: None, 0: "half", 1: "quad", 2: "tile"}
+
+
+def last_launch_shapes():
+    """(forward, backward) kernel shapes of the process's last blend launches (lr_last_launch_shapes)."""
+    f, b = ctypes.c_int(-1), ctypes.c_int(-1)
+    lib().lr_last_launch_shapes(ctypes.byref(f), ctypes.byref(b))
+    return FWD_SHAPES.get(f.value, f.value), BWD_SHAPES.get(b.value, b.value)
 
 
 def profile_enable(on=True):

@@ -75,7 +75,16 @@ def _write_hash_header():
     return path
 
 
-def build(force=False, verbose=False):
+DIAG_LIBDIR = os.path.join(_HERE, "lib_diag")      # the diagnostics build (retired kernels, LR_* environment overrides): tools only
+
+
+def build(force=False, verbose=False, diagnostics=False):
+    """The product library lib/liblucid_raster.so, or with diagnostics=True the same sources with -DLR_DIAGNOSTICS into
+    lib_diag/liblucid_raster.so (A/B partners of tools/ab_bench.py; never loaded unless LR_LIB_DIR says so, tools/diag_env.sh)."""
+    libdir = DIAG_LIBDIR if diagnostics else LIBDIR
+    objdir = os.path.join(libdir, "obj")
+    lib_path = os.path.join(libdir, "liblucid_raster.so")
+    os.makedirs(objdir, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     cc = hipcc()
     hash_header = _write_hash_header()
@@ -84,7 +93,9 @@ def build(force=False, verbose=False):
     procs = []
     for src, extra in SOURCES.items():
         sp = os.path.join(CSRC, src)
-        op = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        op = os.path.join(objdir, src.replace(".hip", ".o"))
+        if diagnostics:
+            extra = extra + ["-DLR_DIAGNOSTICS"]
         objs.append(op)
         deps = [sp] + headers + ([hash_header] if src == "api.hip" else [])
         if force or _stale(op, deps):
@@ -101,12 +112,12 @@ def build(force=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {s} ---\n{o}" for s, o in failed))
-    if force or procs or _stale(LIB_PATH, objs):
-        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs
+    if force or procs or _stale(lib_path, objs):
+        cmd = [cc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB_PATH
+    return lib_path
 
 
 EXT_SRC = os.path.join(CSRC, "torch_ext.cpp")
@@ -144,6 +155,9 @@ def build_ext(force=False, verbose=False):
 
 
 if __name__ == "__main__":
+    if "--diagnostics" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv, diagnostics=True))
+        sys.exit(0)
     path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv)
     print(path)
     print(build_ext(force="--force" in sys.argv, verbose="--verbose" in sys.argv or "-v" in sys.argv))

@@ -56,7 +56,9 @@ struct GeomHeader {
     uint32_t bin_bound;             // instance count the binning buffer was laid out for (R or capacity)
     uint32_t num_compact;           // Gaussians that emit at least one instance (length of the compacted arrays)
     uint32_t n_seg;                 // list segments beyond the first of every tile (BWD_SEG, below): entries of BinLayout::seg_list
-    uint32_t reserved[50];
+    uint32_t bwd_uncovered;         // set by the one-wave-per-tile blend backward when its launch did not reach every listed segment
+                                    // (lr_backward given a smaller R / binning_capacity than the forward): lr_check and debug mode report it
+    uint32_t reserved[49];
     uint32_t sticky_overflow;       // set (never cleared by lr_forward) when a view overflowed: lr_views_accumulate / lr_views_check
     uint32_t reserved_tail[3];
 };
@@ -402,6 +404,11 @@ int blend_shape(int num_tiles);
 // lr_tune_set("views_in_flight", n)).  Never a correctness input: it picks between kernel shapes with identical results.
 struct ViewsInFlight { explicit ViewsInFlight(int n); ~ViewsInFlight(); int prev; };
 int views_in_flight();
+// shapes of the process's last blend launches (lr_last_launch_shapes): forward 0 quadrant / 1 quadrant with candidate
+// pairs / 2 one wave per tile; backward BLEND_HALF / BLEND_QUAD / BLEND_TILE; -1 = none yet
+void note_fwd_shape(int shape);
+int last_fwd_shape();
+int last_bwd_shape();
 // Tile -> workgroup map of the blend kernels.  Workgroup b runs on XCD b % 8 (each XCD has its own L2):
 //   TILE_MAP_BANDS : XCD x renders the contiguous tile band [x T/8, (x+1) T/8): Gaussians that straddle neighbouring tiles
 //                    are re-read from the same L2.

@@ -617,6 +617,10 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
     if (hdr->overflow != 0u) return;                                                                                        \
     int tile, seg = seg_on ? 0 : -1;                                                                                        \
     uint32_t slot = 0u;                                                                                                     \
+    /* a launch that does not reach every listed segment (the caller's R / binning_capacity was smaller than its forward's): \
+       the gradients of the uncovered instances are missing -- said out loud (GeomHeader::bwd_uncovered: lr_check, debug) */ \
+    if (blockIdx.x == 0 && threadIdx.x == 0)                                                                                \
+        const_cast<GeomHeader*>(hdr)->bwd_uncovered = (seg_on && hdr->n_seg > gridDim.x - (uint32_t)grid_tiles) ? 1u : 0u;  \
     if ((int)blockIdx.x < grid_tiles) {                                                                                     \
         tile = blend_tile(tile_map, num_tiles);                                                                             \
         if (tile < 0) return;                                                                                               \
@@ -650,6 +654,7 @@ k_render_bwd_tile(LR_BWD_SEG_PARAMS)
     LR_BWD_KERNEL_BODY_ONE(LR_ITEM)
 #undef LR_ITEM
 }
+#ifdef LR_DIAGNOSTICS
 // the compiler's own register budget (69 VGPRs, 7 waves per SIMD), 64 staged Gaussians per round: A/B partner (bwd_red = 3)
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_render_bwd_tile7(LR_BWD_SEG_PARAMS)
@@ -658,15 +663,29 @@ k_render_bwd_tile7(LR_BWD_SEG_PARAMS)
     LR_BWD_KERNEL_BODY(LR_ITEM)
 #undef LR_ITEM
 }
+#endif
 
 #undef LR_BWD_PARAMS
 #undef LR_BWD_PASS
 
 }  // namespace
 
+// Diagnostics builds only (-DLR_DIAGNOSTICS: `python -m luciddreamer_amd.build --diagnostics`, tools/ab_bench.py): an
+// environment variable read once per process forces a variant without a call.  The product library reads none.
+static int env_knob(const char* name)
+{
+#ifdef LR_DIAGNOSTICS
+    const char* e = getenv(name);
+    return e ? atoi(e) : -1;
+#else
+    (void)name;
+    return -1;
+#endif
+}
+
 int blend_tile_map(int num_tiles)
 {
-    static const int forced = [] { const char* e = getenv("LR_TILE_MAP"); return e ? atoi(e) : -1; }();
+    static const int forced = env_knob("LR_TILE_MAP");
     if (tune_get(TUNE_TILE_MAP) >= 0) return tune_get(TUNE_TILE_MAP);
     if (forced >= 0) return forced;
     return num_tiles <= 4096 ? TILE_MAP_PLAIN : TILE_MAP_BANDS;
@@ -679,7 +698,7 @@ int views_in_flight() { return max(g_views_in_flight, tune_get(TUNE_VIEWS_IN_FLI
 
 int blend_shape(int num_tiles)
 {
-    static const int forced = [] { const char* e = getenv("LR_BLEND_QUAD_BWD"); return e ? atoi(e) : -1; }();
+    static const int forced = env_knob("LR_BLEND_QUAD_BWD");
     if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD);
     if (forced >= 0) return forced;
     // The backward blend pays its cross-lane reduction per wave and candidate.  Small images (every workgroup resident at once:
@@ -697,6 +716,13 @@ int blend_shape(int num_tiles)
     return views_in_flight() >= 2 ? BLEND_TILE : BLEND_HALF;
 }
 
+// shapes of the process's last blend launches (lr_last_launch_shapes: tests assert which kernels a configuration ran; process-wide,
+// not per thread: the autograd engine issues a backward from its own thread)
+static volatile int g_last_fwd_shape = -1, g_last_bwd_shape = -1;
+void note_fwd_shape(int shape) { g_last_fwd_shape = shape; }
+int last_fwd_shape() { return g_last_fwd_shape; }
+int last_bwd_shape() { return g_last_bwd_shape; }
+
 void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
@@ -706,46 +732,53 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    // LR_BWD_LDS_PAD=<bytes> of unused dynamic LDS lowers the occupancy of the 2-wave shape (diagnostics).  Round 1 ran it
-    // with 8 KB (5 waves per SIMD instead of 7) inside the multi-stream view loop, which then gained 3 % because the other
-    // streams' memory-bound kernels found room beside it; with round 2's binning that no longer holds: alternated on one box,
-    // no pad wins everywhere (C3 +0.8 %, C2 +4.3 %, dense box +1.8 %, C4 shape +2.8 %, fused-loss step +1.4 %).
-    static const int forced_pad = [] { const char* e = getenv("LR_BWD_LDS_PAD"); return e ? atoi(e) : -1; }();
-    const int pad = forced_pad >= 0 ? forced_pad : 0;
-    // lr_tune_set("bwd_red", 0) / LR_BWD_RED=0 selects the round-2 reduction (diagnostics, A/B runs)
-    static const int forced_red = [] { const char* e = getenv("LR_BWD_RED"); return e ? atoi(e) : -1; }();
+    // lr_tune_set("bwd_red", 4): every wave walks the copy of the loop WITH the `pos < last` test (the copy a wave with a stopped
+    // pixel takes: tests put whole scenes through it).  Diagnostics builds: 0 = the round-2 reduction, 3 = the 7-waves-per-SIMD
+    // tile kernel, LR_BWD_LDS_PAD=<bytes> of unused dynamic LDS lowers the occupancy of the 2-wave shape.
+    static const int forced_red = env_knob("LR_BWD_RED");
     const int red = tune_get(TUNE_BWD_RED) >= 0 ? tune_get(TUNE_BWD_RED) : forced_red;
-    const bool merge = red != 0;
-    // lr_tune_set("bwd_red", 4): every wave walks the copy of the loop WITH the `pos < last` test (A/B partner of the default)
     const int force_check = red == 4 ? 1 : 0;
+#ifdef LR_DIAGNOSTICS
+    static const int forced_pad = env_knob("LR_BWD_LDS_PAD");
+    const int pad = forced_pad >= 0 ? forced_pad : 0;
+    const bool merge = red != 0;
+#else
+    constexpr int pad = 0;
+#endif
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
     int shape = blend_shape(num_tiles);
     const bool strict = tune_get(TUNE_STRICT) > 0;
-    // Segments (common.h BWD_SEG): on by default; lr_tune_set("bwd_seg", 0) / LR_BWD_SEG=0 = one workgroup walks a tile's
-    // whole list (rounds 1-4; A/B partner).  The launch adds workgroups for the listed segments up to the bound the host
+    // Segments (common.h BWD_SEG): on by default; lr_tune_set("bwd_seg", 0) = one workgroup walks a tile's whole list (rounds
+    // 1-4: what the segment tests compare with).  The launch adds workgroups for the listed segments up to the bound the host
     // knows, capped (a workgroup strides over the list, so the cap costs nothing but balance on absurdly long lists).
-    static const int forced_seg = [] { const char* e = getenv("LR_BWD_SEG"); return e ? atoi(e) : -1; }();
+    static const int forced_seg = env_knob("LR_BWD_SEG");
     const int seg_on = (tune_get(TUNE_BWD_SEG) >= 0 ? tune_get(TUNE_BWD_SEG) : (forced_seg >= 0 ? forced_seg : 1)) != 0 ? 1 : 0;
     // (the one-wave-per-tile shape takes exactly one listed segment per workgroup: no cap there, and it is not used when the
     // caller gave no usable bound -- seg_bound < 0, see lr_backward -- or when segments are off and its workgroup walks the whole list)
     if (shape == BLEND_TILE && seg_on && seg_bound < 0) shape = BLEND_HALF;
+    g_last_bwd_shape = shape;
     const long long cap = shape == BLEND_TILE ? 0x3fffffffll : 262144ll;
     const int extra = seg_on ? (int)(seg_bound < 1 ? 1024 : seg_bound > cap ? cap : seg_bound) : 0;
     const dim3 g(grid + extra);
 #define LR_SEG_ARGS LR_BWD_ARGS, tile_seg0, c_final, grid, seg_on
     if (shape == BLEND_TILE) {
         if (strict) hipLaunchKernelGGL(k_render_bwd_tile<true>, g, dim3(64), 0, s, LR_SEG_ARGS);
-        else if (tune_get(TUNE_BWD_RED) == 3) hipLaunchKernelGGL(k_render_bwd_tile7, g, dim3(64), 0, s, LR_SEG_ARGS);
+#ifdef LR_DIAGNOSTICS
+        else if (red == 3) hipLaunchKernelGGL(k_render_bwd_tile7, g, dim3(64), 0, s, LR_SEG_ARGS);
+#endif
         else hipLaunchKernelGGL(k_render_bwd_tile<false>, g, dim3(64), 0, s, LR_SEG_ARGS);
     } else if (strict) {
         if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, true, true>), g, dim3(256), 0, s, LR_SEG_ARGS);
         else hipLaunchKernelGGL((k_render_bwd<false, true, true>), g, dim3(128), pad, s, LR_SEG_ARGS);
-    } else if (shape == BLEND_QUAD) {
-        if (merge) hipLaunchKernelGGL((k_render_bwd<true, true>), g, dim3(256), 0, s, LR_SEG_ARGS);
-        else hipLaunchKernelGGL((k_render_bwd<true, false>), g, dim3(256), 0, s, LR_SEG_ARGS);
-    } else {
-        if (merge) hipLaunchKernelGGL((k_render_bwd<false, true>), g, dim3(128), pad, s, LR_SEG_ARGS);
+#ifdef LR_DIAGNOSTICS
+    } else if (!merge) {                    // the round-2 reduction (three row sums, three LDS float atomics into a shared copy)
+        if (shape == BLEND_QUAD) hipLaunchKernelGGL((k_render_bwd<true, false>), g, dim3(256), 0, s, LR_SEG_ARGS);
         else hipLaunchKernelGGL((k_render_bwd<false, false>), g, dim3(128), pad, s, LR_SEG_ARGS);
+#endif
+    } else if (shape == BLEND_QUAD) {
+        hipLaunchKernelGGL((k_render_bwd<true, true>), g, dim3(256), 0, s, LR_SEG_ARGS);
+    } else {
+        hipLaunchKernelGGL((k_render_bwd<false, true>), g, dim3(128), pad, s, LR_SEG_ARGS);
     }
 #undef LR_SEG_ARGS
 #undef LR_BWD_ARGS

@@ -416,6 +416,7 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const bool tile_shape = knob >= 0 ? knob == 2 : (num_tiles > 3072 && views_in_flight() >= 2 && !long_lists);
     const bool pair = knob >= 0 ? knob == 1 : num_tiles <= 3072;
     const bool strict = tune_get(TUNE_STRICT) > 0;
+    note_fwd_shape(tile_shape ? 2 : pair ? 1 : 0);
 #define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
                     quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
     if (tile_shape) {

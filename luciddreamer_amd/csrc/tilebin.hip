@@ -139,6 +139,7 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
         hdr->bin_bound = capacity != 0 ? capacity : total;   // what the binning buffer is laid out for
         hdr->num_compact = run_c;
         hdr->n_seg = 0u;                        // the blend forward reserves its list segments on it
+        hdr->bwd_uncovered = 0u;
         if (over) hdr->sticky_overflow = 1u;
         if (log_slot != nullptr) {
             // the library's forward log (host-visible memory, api.hip ForwardLog): the header words first, the tag last,
@@ -423,6 +424,7 @@ k_part(int gx, int gy, int bins, int sub_shift, int slot_bits, int own_max, cons
 // independent, and the groups are joined through LDS: two memory round trips for the kernel instead of one per eight rows
 // of one thread walking a whole column (8.4 us at C3: 32 workgroups, twelve dependent rounds).  Lanes 0-15 of a quarter wave
 // touch 16 consecutive words of one row.
+#ifdef LR_DIAGNOSTICS        // retired in round 5 (the count kernel reserves its ranges itself); A/B partner of the diagnostics build
 constexpr int SCAN1_BINS = 16, SCAN1_GROUPS = 16, SCAN1_ROWS = PART_BLOCKS_MAX / SCAN1_GROUPS;
 __global__ void __launch_bounds__(SCAN1_BINS * SCAN1_GROUPS)
 k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict__ part_hist, uint32_t* __restrict__ bin_total)
@@ -455,6 +457,7 @@ k_part_scan1(int bins, const GeomHeader* __restrict__ hdr, uint32_t* __restrict_
     }
     if (g == 0) bin_total[bin] = total;
 }
+#endif
 
 // -------------------------------------------------------------------------------------------
 // sorting one bin.  All comparators ascending (the first step of every merge mirrors the block), so positions
@@ -767,16 +770,22 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     const int own_max = tune_get(TUNE_WALK_OWN) >= 0 ? tune_get(TUNE_WALK_OWN) : 12;
     // lr_tune_set("part_scan", 1): the count kernel leaves per-workgroup counts and k_part_scan1 turns them into bases (rounds
     // 2-4; A/B partner); default: the count kernel reserves its ranges itself (bin_total arrives zeroed from the scan kernel)
+#ifdef LR_DIAGNOSTICS
     const int reserve = tune_get(TUNE_PART_SCAN) == 1 ? 0 : 1;
+#else
+    constexpr int reserve = 1;
+#endif
     if (t) t->mark(0, s);
     hipLaunchKernelGGL(k_part<0>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,
                        inst_gid, words, clear_words, n_clear, reserve);
+#ifdef LR_DIAGNOSTICS
     if (!reserve) {
         if (t) t->mark(1, s);
         hipLaunchKernelGGL(k_part_scan1, dim3((pp.bins + SCAN1_BINS - 1) / SCAN1_BINS), dim3(SCAN1_BINS * SCAN1_GROUPS), 0, s, pp.bins, hdr,
                            part_hist, bin_total);
     }
+#endif
     if (t) t->mark(2, s);                                   // closes the stage that is open, opens the scatter's
     hipLaunchKernelGGL(k_part<1>, dim3((unsigned)nb), dim3(PART_THREADS), lds, s, gx, gy, pp.bins, pp.sub_shift, slot_bits,
                        own_max, vis_list, offsets, hitrec, rec, radii, hdr, part_hist, bin_total, bin_start, ranges, big_queue,

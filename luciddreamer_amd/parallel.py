@@ -276,10 +276,8 @@ class ShardedAdam:
             shard.copy_(mine[self.lo:self.hi])
 
     @torch.no_grad()
-    def step(self, async_gather: bool = False):
-        """Gradients of this rank's views are in self.grads.flat (accumulated); afterwards every rank holds the updated
-        parameters.  The bucket is left as it was (zero it before the next step: FlatGrads.zero_).  async_gather: return the
-        handle of the parameter all-gather instead of joining it (None on one rank)."""
+    def reduce_and_update(self):
+        """First half of step(): reduce-scatter of the bucket and Adam on this rank's shard (no parameter leaves the rank yet)."""
         self.step_count += 1
         flat_g, flat_p = self.grads.flat, self.params.flat
         if self.world > 1:
@@ -291,13 +289,27 @@ class ShardedAdam:
         pieces = [(p_shard[o:o + n], g[o:o + n], self.exp_avg[o:o + n], self.exp_avg_sq[o:o + n], self.lrs[t])
                   for o, n, t in self.pieces]
         self.adam_fn(pieces, self.betas[0], self.betas[1], self.eps, self.step_count)
+
+    @torch.no_grad()
+    def gather(self, async_op: bool = False):
+        """Second half: all-gather of the flat parameter buffer, in place (rank r's input IS slice r of the output).
+        async_op: the collective is left in flight and its handle returned -- the caller decides what may run before the
+        parameters of THIS bucket are needed again (None on one rank)."""
         if self.world > 1:
-            # in place: rank r's input IS slice r of the output.  async_gather: the collective is left in flight and its
-            # handle returned -- the caller decides what may run before the parameters of THIS bucket are needed again
-            if async_gather:
+            flat_p = self.params.flat
+            p_shard = flat_p[self.lo:self.hi]
+            if async_op:
                 return dist.all_gather_into_tensor(flat_p, p_shard, async_op=True)
             dist.all_gather_into_tensor(flat_p, p_shard)
         return None
+
+    @torch.no_grad()
+    def step(self, async_gather: bool = False):
+        """Gradients of this rank's views are in self.grads.flat (accumulated); afterwards every rank holds the updated
+        parameters.  The bucket is left as it was (zero it before the next step: FlatGrads.zero_).  async_gather: return the
+        handle of the parameter all-gather instead of joining it (None on one rank)."""
+        self.reduce_and_update()
+        return self.gather(async_gather)
 
 
 class SplitShardedAdam:
@@ -353,12 +365,19 @@ class SplitShardedAdam:
     @torch.no_grad()
     def step(self):
         """Both buckets: reduce-scatter + Adam on the shard; all-gather of the geometry (joined here), all-gather of the
-        appearance left in flight (joined by wait(), or by the next step())."""
+        appearance left in flight (joined by wait(), or by the next step()).
+
+        ORDER OF ISSUE matters: RCCL runs the collectives of a process group in the order they were issued, on one
+        communicator stream -- an all-gather issued early holds up everything issued after it, whatever `async_op` says.  So
+        the geometry bucket goes first and completely (reduce-scatter, Adam, all-gather: 19 % of the bytes), then the
+        appearance bucket's reduce-scatter and Adam, and its all-gather is the LAST collective issued: joining the geometry
+        waits for nothing of the appearance bucket, and what is left in flight when step() returns really is the SH gather
+        (rounds 4-5 issued it first; on RCCL the geometry join then waited for it and the window was empty -- ADVICE r5)."""
         self.wait()
-        # the big bucket first: its reduce-scatter and Adam are issued before the small bucket's collectives, and its
-        # all-gather is the one left running
-        self._pending = self.appearance.step(async_gather=True)
-        self.geometry.step()
+        self.geometry.reduce_and_update()
+        self.geometry.gather()
+        self.appearance.reduce_and_update()
+        self._pending = self.appearance.gather(async_op=True)
         return self._pending
 
     def wait(self):

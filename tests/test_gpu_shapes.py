@@ -1,6 +1,6 @@
 """The three execution shapes of the blend backward kernel (render_bwd.hip: 2 waves per tile with two pixels per lane,
 one 8x8 quadrant per wave, or one wave per tile with four pixels per lane) against the CPU oracle on the same scenes.  The library picks the shape from the tile count
-and reads LR_BLEND_QUAD_BWD once per process, so each shape runs in its own interpreter."""
+(lr_tune_set("blend_quad", .) forces one); each shape runs in its own interpreter with the knob set before anything else."""
 import os
 import subprocess
 import sys
@@ -12,9 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SCRIPT = r"""
+import os
 import numpy as np, torch
-from luciddreamer_amd import synthetic
+from luciddreamer_amd import _lib, synthetic
 from tests import helpers as hp
+_lib.tune_set("blend_quad", int(os.environ["SHAPE_UNDER_TEST"]))
 dev = torch.device("cuda:0")
 for (P, W, H, seed) in ((20000, 320, 200, 0), (3000, 333, 77, 1), (50000, 640, 360, 2)):
     cam, cloud = hp.box_setup(P, W, H, seed=seed)
@@ -26,13 +28,14 @@ for (P, W, H, seed) in ((20000, 320, 200, 0), (3000, 333, 77, 1), (50000, 640, 3
     # every row within 1e-4 of its tensor's maximum; rows beyond (at most 8, at most 1e-3) must sit on a pixel the oracle flags
     # as within float32 rounding of a discrete decision (helpers.compare_grads_by_row)
     hp.compare_grads_by_row(hip, ref, P, max_outliers=8)
+    assert _lib.last_launch_shapes()[1] == {0: "half", 1: "quad", 2: "tile"}[int(os.environ["SHAPE_UNDER_TEST"])]
 print("SHAPE-OK")
 """
 
 
 @pytest.mark.parametrize("quad", ["0", "1", "2"])
 def test_blend_backward_shape_matches_oracle(hip_device, quad):
-    env = dict(os.environ, LR_BLEND_QUAD_BWD=quad, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env = dict(os.environ, SHAPE_UNDER_TEST=quad, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
     r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "SHAPE-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 

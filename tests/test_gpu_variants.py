@@ -12,10 +12,18 @@ from tests import helpers as hp
 pytestmark = pytest.mark.gpu
 
 
+def _needs_diagnostics():
+    """Retired kernels (the round-2 LDS-atomic reduction, the scanned partition) are compiled into the diagnostics build only
+    (`python -m luciddreamer_amd.build --diagnostics`, tools/diag_env.sh python -m pytest ...): the product library ships none."""
+    if not _lib.diagnostics_build():
+        pytest.skip("retired kernel: diagnostics build only (tools/diag_env.sh)")
+
+
 @pytest.fixture(autouse=True)
 def _restore_knobs():
     yield
-    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan", "bwd_seg", "fwd_pair"):
+    for k in ("preprocess", "bwd_red", "hit_mask", "walk_own", "tsort", "part_scan", "bwd_seg", "fwd_pair", "blend_quad",
+              "views_in_flight", "strict"):
         _lib.tune_set(k, -1)
 
 
@@ -58,6 +66,7 @@ def test_pooled_preprocess_raw_mode_and_precomputed_inputs(hip_device):
 
 @pytest.mark.parametrize("W,H", [(640, 360), (1280, 720)])      # QUAD shape / two-wave shape of k_render_bwd
 def test_backward_reductions_agree(hip_device, W, H):
+    _needs_diagnostics()
     cam, cloud = hp.box_setup(40_000, W, H)
     g = synthetic.upstream_grad(H, W)
     outs = []
@@ -88,7 +97,7 @@ def test_check_free_candidate_loop_is_bit_identical(hip_device, shape, scale_mul
     try:
         _lib.tune_set("bwd_red", 4)
         a = _run(cloud, cam, hip_device, g)
-        _lib.tune_set("bwd_red", 1)
+        _lib.tune_set("bwd_red", -1)
         b = _run(cloud, cam, hip_device, g)
     finally:
         _lib.tune_set("bwd_red", -1)
@@ -242,9 +251,11 @@ def test_backward_is_bit_repeatable_over_many_runs(hip_device, W, H, red):
     """Forty runs of the same view give the same gradients, bit for bit, with either reduction.  This is the test that would
     have caught the missing `s_waitcnt lgkmcnt(0)` in front of the barrier that closes a batch of k_render_bwd (common.h
     lds_barrier): with the LDS-atomic reduction one Gaussian's colour gradient differed in ~5 % of the runs."""
+    if red == 0:
+        _needs_diagnostics()
     cam, cloud = hp.box_setup(40_000, W, H)
     g = synthetic.upstream_grad(H, W)
-    _lib.tune_set("bwd_red", red)
+    _lib.tune_set("bwd_red", red if red == 0 else -1)
     first = _run(cloud, cam, hip_device, g)
     for _ in range(40):
         again = _run(cloud, cam, hip_device, g)
@@ -281,6 +292,7 @@ def test_ranges_reserved_by_the_count_kernel_give_the_lists_of_the_scanned_rows(
     cursor -- which workgroup gets which range depends on arrival; lr_tune_set("part_scan", 1): per-workgroup counts and a scan
     kernel (rounds 2-4), ranges in workgroup order.  The per-bin sort is a total order on the words, so lists, images and
     gradients must be the same bits either way -- also run to run (several passes: arrival order differs)."""
+    _needs_diagnostics()
     cloud = synthetic.make_cloud(P, kind, 11)
     if scale_mult != 1.0:
         cloud["scales"] = cloud["scales"] * scale_mult

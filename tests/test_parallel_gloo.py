@@ -199,7 +199,27 @@ def _split_worker(rank, world, port, out_dir):
         for p, q, g in zip(params, twin, _fake_view_grads(params, rank, world, 7, it)):
             p.grad.add_(g)
             q.grad.add_(g)
-        handle = split.step()
+        # RCCL runs a group's collectives in issue order on one stream: what step() leaves in flight is only a window if the
+        # appearance all-gather is the LAST collective issued and the geometry bucket is complete before the appearance bucket
+        # puts anything on the links.  Recorded: (collective, number of floats).
+        issued = []
+        real_rs, real_ag = dist.reduce_scatter_tensor, dist.all_gather_into_tensor
+
+        def rs(out, inp, *a, **k):
+            issued.append(("reduce_scatter", inp.numel()))
+            return real_rs(out, inp, *a, **k)
+
+        def ag(out, inp, *a, **k):
+            issued.append(("all_gather", out.numel(), bool(k.get("async_op", False))))
+            return real_ag(out, inp, *a, **k)
+        dist.reduce_scatter_tensor, dist.all_gather_into_tensor = rs, ag
+        try:
+            handle = split.step()
+        finally:
+            dist.reduce_scatter_tensor, dist.all_gather_into_tensor = real_rs, real_ag
+        n_geo, n_app = split.grads_geometry.flat.numel(), split.grads_appearance.flat.numel()
+        assert issued == [("reduce_scatter", n_geo), ("all_gather", n_geo, False), ("reduce_scatter", n_app),
+                          ("all_gather", n_app, True)], issued
         # step() has joined the geometry gather: those parameters are final on every rank while the SH gather may still run
         geometry_ready.append([p.detach().clone() for p in params[:4]])
         assert (handle is None) == (world == 1)
