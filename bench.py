@@ -270,12 +270,16 @@ class Workload:
             self.batch.check()
 
 
-def timed(step, n_steps, world, dev):
+def timed(step, n_steps, world, dev, collect=True):
     """K steps between barrier + synchronize on both sides; MAX over ranks.  Returns (seconds, host ms to issue a step)."""
     # before the clock: what the set-up of this leg created is still in the Python collector's young generations, and the first
-    # collection inside a timed region of a few milliseconds would walk all of it (50-90 ms: profiles/r04q_loop_drift.txt)
+    # collection inside a timed region of a few milliseconds would walk all of it (50-90 ms: profiles/r04q_loop_drift.txt).
+    # run_leg collects BEFORE its warm-up steps instead (collect=False here): a collection between the warm-up and the clock
+    # leaves the GPU idle for those 50-90 ms, and the first steps after an idle stretch run below the sustained clock
+    # (profiles/r06f_step_series.txt: +20 / +9 / +6 / +5 % on the first four steps after 2 s of idle)
     import gc
-    gc.collect()
+    if collect:
+        gc.collect()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
@@ -295,10 +299,12 @@ def timed(step, n_steps, world, dev):
 
 
 def run_leg(wl, api, exact, streams, steps, warmup, world, dev, fused=True):
+    import gc
     step = wl.make_step(api, exact, streams, fused)
+    gc.collect()                                    # (see timed())
     for _ in range(warmup):
         step()
-    dt, host_ms = timed(step, steps, world, dev)
+    dt, host_ms = timed(step, steps, world, dev, collect=False)
     wl.finish()
     return wl.total_views * steps / dt, dt / steps * 1e3, host_ms, step
 
@@ -724,6 +730,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU fallback for the product path")
+    forced = os.environ.get("LR_TUNE")                      # "knob=value,...": counter passes of a candidate kernel (tools/pmc_run.sh)
+    if forced:
+        from luciddreamer_amd import _lib
+        for kv in forced.split(","):
+            _lib.tune_set(kv.split("=")[0].strip(), int(kv.split("=")[1]))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args.gpus))            # plain `python bench.py --gpus N`: start the N ranks ourselves
     rank, world, dev = parallel.init_distributed()
@@ -860,6 +871,8 @@ def main():
                     "streams_per_rank": args.streams,
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
+        if os.environ.get("LR_TUNE"):
+            cfg["forced_kernel_variants"] = os.environ["LR_TUNE"]
         # the figures beside the headline that a reader of the driver's record needs (the driver keeps `config` whole):
         # the same step in strict mode, the API LucidDreamer calls, the >= 1 s repeat of the headline step, LucidDreamer's own
         # loop after install(), and whether the headline's own kernels met the oracle at this size
