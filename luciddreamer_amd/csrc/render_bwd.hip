@@ -517,8 +517,6 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
     const uint32_t last0 = wave_max_u32(P0.last), last1 = wave_max_u32(P1.last);
     const uint32_t last2 = wave_max_u32(P2.last), last3 = wave_max_u32(P3.last);
     const uint32_t tile_last = max(max(last0, last1), max(last2, last3));
-    const float ddelx_dx = (float)(0.5 * W);     // backward.cu:473-474 (double product, rounded once)
-    const float ddely_dy = (float)(0.5 * H);
 
     const int row = l >> 4;
     const int col_a = (row == 0) ? 0 : (row == 1) ? 2 : (row == 2) ? 1 : 3;     // as k_render_bwd (reduce8 / row_merge3 layout)
@@ -546,20 +544,25 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
             continue;
         }
         lds_barrier();
+        // the lane's staging / flush addresses are formed HERE, per round, from a lane index the optimiser cannot see through:
+        // hoisted out of the loop they are seven more live registers in a kernel that has 64, i.e. seven spilled dwords per
+        // lane (15 MB of scratch stores per 1080p view, round 6) for a handful of integer operations per round
+        int lv = l;
+        asm volatile("" : "+v"(lv));
         uint32_t my_hit = 0u;
-        if (l < cnt) {
-            const uint32_t e = point_list[range.x + (pos_hi - l)];
-            my_hit = quad_hits[range.x + (pos_hi - l)];
+        if (lv < cnt) {
+            const uint32_t e = point_list[range.x + (pos_hi - lv)];
+            my_hit = quad_hits[range.x + (pos_hi - lv)];
             const uint32_t id = inst_gid[e];
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
-            s_q0[l] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-            *reinterpret_cast<float2*>(&s_q1[l]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
-            s_q2[l] = make_float4(b.z, b.w, c.x, 0.f);
-            s_id[l] = e;
+            s_q0[lv] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
+            *reinterpret_cast<float2*>(&s_q1[lv]) = STRICT ? make_float2(b.x, b.y) : make_float2((-0.5f * LOG2E) * b.x, b.y);
+            s_q2[lv] = make_float4(b.z, b.w, c.x, 0.f);
+            s_id[lv] = e;
         }
-        if (l < BATCH) {
-            float4* z = reinterpret_cast<float4*>(&s_acc[l * 12]);
+        if (lv < BATCH) {
+            float4* z = reinterpret_cast<float4*>(&s_acc[lv * 12]);
             z[0] = make_float4(0.f, 0.f, 0.f, 0.f); z[1] = z[0]; z[2] = z[0];
         }
         lds_barrier();
@@ -617,17 +620,21 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
             if (merge_writer) s_acc[jo + merge_off] = rc;
         }
         lds_barrier();
-        if (l < cnt) {
+        if (lv < cnt) {
+            int Wv = W, Hv = H;
+            asm volatile("" : "+s"(Wv), "+s"(Hv));               // (as lv: formed per round, not kept in two registers)
+            const float ddelx_dx = (float)(0.5 * Wv);            // backward.cu:473-474 (double product, rounded once)
+            const float ddely_dy = (float)(0.5 * Hv);
             float a9[12];
 #pragma unroll
-            for (int k = 0; k < 12; k++) a9[k] = s_acc[l * 12 + k];
-            const float4 q0 = s_q0[l]; const float2 q1 = *reinterpret_cast<const float2*>(&s_q1[l]);
+            for (int k = 0; k < 12; k++) a9[k] = s_acc[lv * 12 + k];
+            const float4 q0 = s_q0[lv]; const float2 q1 = *reinterpret_cast<const float2*>(&s_q1[lv]);
             const float db = (a9[8] + a9[9]) + (a9[10] + a9[11]);
             const float ca = STRICT ? q0.z : (-2.0f * LN2) * q0.z, cb = STRICT ? q0.w : -LN2 * q0.w,
                         cc = STRICT ? q1.x : (-2.0f * LN2) * q1.x, o = q1.y;
             const float sx = a9[0], sy = a9[1], h = -0.5f;          // as k_render_bwd: the sums carry the opacity factor
             const float dopac = o > 0.f ? a9[5] * __builtin_amdgcn_rcpf(o) : 0.f;      // 1 ulp: the sum itself carries more
-            float4* slot = inst_grad + 3 * (size_t)s_id[l];
+            float4* slot = inst_grad + 3 * (size_t)s_id[lv];
             slot[0] = make_float4((-ca * sx - cb * sy) * ddelx_dx, (-cc * sy - cb * sx) * ddely_dy, h * a9[2], h * a9[3]);
             slot[1] = make_float4(h * a9[4], dopac, a9[6], a9[7]);
             slot[2] = make_float4(db, 0.f, 0.f, 0.f);

@@ -257,8 +257,8 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 // same order as the quadrant kernel: the same bits (tests/test_gpu_variants.py).
 constexpr int TSTAGE = 64;
 template <bool STRICT>
-__global__ void __launch_bounds__(64)
-k_render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
+__device__ __forceinline__ void
+render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
                   const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
                   const GaussRec* __restrict__ rec,
                   const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
@@ -277,8 +277,6 @@ k_render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2
     const int x0 = tx * TILE_X, y0 = ty * TILE_Y;
     const int pxl = x0 + (l & 7), pyt = y0 + (l >> 3);                // the lane's pixel in quadrant 0; + 8 for the right / lower ones
     const float pxf[2] = { (float)pxl, (float)(pxl + 8) }, pyf[2] = { (float)pyt, (float)(pyt + 8) };
-    const float bx[2][2] = { { (float)x0, (float)(x0 + 7) }, { (float)(x0 + 8), (float)(x0 + 15) } };
-    const float by[2][2] = { { (float)y0, (float)(y0 + 7) }, { (float)(y0 + 8), (float)(y0 + 15) } };
 
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -325,6 +323,13 @@ k_render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2
         bool hit[4] = { false, false, false, false };
         lds_barrier();                                                // (the previous round's reads are done: one wave, no waiting)
         if (l < cnt) {
+            // the quadrants' boxes are formed here, per round, from tile coordinates the optimiser cannot see through: kept
+            // across the candidate loop they are eight more live registers (the tile's corner is uniform, but float conversions
+            // live in vector registers)
+            int x0v = x0, y0v = y0;
+            asm volatile("" : "+s"(x0v), "+s"(y0v));
+            const float bx[2][2] = { { (float)x0v, (float)(x0v + 7) }, { (float)(x0v + 8), (float)(x0v + 15) } };
+            const float by[2][2] = { { (float)y0v, (float)(y0v + 7) }, { (float)(y0v + 8), (float)(y0v + 15) } };
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             const float4 q0 = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
@@ -386,6 +391,25 @@ k_render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2
         if (n_seg > 0) c_final[pix] = make_float4(fr, fg, fb, 0.f);
         out_depth[pix] = (A[q].acc > 0.5f) ? A[q].D / A[q].acc : 0.0f;         // forward.cu:384-388
     }
+}
+#define LR_FWD_TILE_PARAMS int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,                 \
+                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,                              \
+                  const GaussRec* __restrict__ rec,                                                                            \
+                  const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,                 \
+                  float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,               \
+                  GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,                       \
+                  uint32_t* __restrict__ tile_seg0, float4* __restrict__ c_final
+#define LR_FWD_TILE_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color,  \
+                  out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
+// 64 registers -> 8 waves per SIMD: the 8160 tiles of a 1080p view are all resident at once, as in the backward's TILE shape
+// (round 6; with the compiler's own budget, 66-72 registers and 7 waves per SIMD, the last 992 waves waited for the first 7168:
+// lone view C3 62.3 -> 59.0 us, C2 101 -> 92 us, dense 1080p 366 -> 342 us, three views in flight equal;
+// profiles/r06h_ab_fwdtile8.json).  The quadrant boxes formed per round are what made room (render_fwd_tile).
+template <bool STRICT>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_vgpr(64)))
+k_render_fwd_tile(LR_FWD_TILE_PARAMS)
+{
+    render_fwd_tile<STRICT>(LR_FWD_TILE_PASS);
 }
 
 }  // namespace
