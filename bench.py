@@ -246,7 +246,7 @@ class Workload:
                 batch.run(self.m2d_grad)
             return step
         grads = self.grads = parallel.FlatGrads(self.params)
-        pipe = parallel.ViewStreams(dev, streams)
+        pipe = self.pipe = parallel.ViewStreams(dev, streams)
         means2D, grad_color = self.means2D, self.grad_color
 
         def step():
@@ -789,9 +789,17 @@ def main():
         entry_points = {}
         for key, api, exact in (("drop_in_views_per_s", "autograd", False), ("exact_mode_views_per_s", "autograd", True),
                                 ("views_loss_views_per_s", "views-loss", False)):
+            if hasattr(wl, "pipe"):
+                del wl.pipe
             v, ms, host, _ = run_leg(wl, api, exact, args.streams, args.steps, args.warmup, world, dev, fused)
             entry_points[key] = round(v, 1)
             entry_points[key.replace("_views_per_s", "_host_issue_ms_per_step")] = round(host, 3)
+            if getattr(wl, "pipe", None) is not None:
+                # of that, the time end_step() spent BLOCKED on the last view's header (policy "recover": the GPU is still working;
+                # the rest is host work: Python, binding, launches) -- over the warm-up and timed steps of the leg
+                waited = wl.pipe.waited_s / max(args.steps + args.warmup, 1) * 1e3
+                entry_points[key.replace("_views_per_s", "_host_blocked_on_last_header_ms_per_step")] = round(waited, 3)
+                entry_points[key.replace("_views_per_s", "_host_work_ms_per_step")] = round(max(host - waited, 0.0), 3)
         # the headline step in STRICT mode (config.set_strict_parity: alpha from the reference's own float operations -- images
         # within 1e-5 on every pixel, no gradient row exempt: `parity.strict_mode`)
         from luciddreamer_amd import config as _cfg
@@ -882,6 +890,7 @@ def main():
             "strict_mode_views_per_s": (entry_points or {}).get("strict_mode_views_per_s"),
             "drop_in_views_per_s": (entry_points or {}).get("drop_in_views_per_s"),
             "drop_in_host_issue_ms_per_step": (entry_points or {}).get("drop_in_host_issue_ms_per_step"),
+            "drop_in_host_work_ms_per_step": (entry_points or {}).get("drop_in_host_work_ms_per_step"),
             "sustained_views_per_s": (sustained or {}).get("views_per_s"),
             "c5_train_loop_ms_per_iter": {k: (c5.get(k) or {}).get("ms_per_iter") for k in
                                           ("this_rasterizer", "this_rasterizer_after_install", "with_optional_pieces",

@@ -91,6 +91,8 @@ check = _C_ext.check
 # the operator with its autograd node compiled (csrc/torch_ext.cpp RasterizeFn); returns (color, radii, depth, geom), the
 # call's num_rendered is read with last_num_rendered()
 rasterize_autograd = _C_ext.rasterize_autograd
+# forward + backward of one view in one call for a caller that holds dL/dcolor up front; [] = an input does not qualify
+rasterize_view_step = _C_ext.rasterize_view_step
 last_num_rendered = _C_ext.last_num_rendered
 
 

@@ -232,6 +232,29 @@ def verify(means3D, rs, ticket) -> bool:
     return over
 
 
+def offer_grad_output(grad_output):
+    """parallel.ViewStreams.run_view: the NEXT rasterizer call on this thread may run its backward right behind its forward
+    with this dL/dcolor (one call into the binding, no autograd node: rasterizer.rasterize_gaussians); None withdraws the
+    offer.  Whether it was taken: grad_output_taken()."""
+    _tls.offered_grad = grad_output
+    _tls.grad_taken = False
+
+
+def offered_grad_output():
+    return getattr(_tls, "offered_grad", None)
+
+
+def mark_grad_output_taken():
+    _tls.offered_grad = None
+    _tls.grad_taken = True
+
+
+def grad_output_taken() -> bool:
+    """True once if the offer of offer_grad_output() was taken (the view's gradients are already accumulated); clears it."""
+    taken, _tls.grad_taken, _tls.offered_grad = getattr(_tls, "grad_taken", False), False, None
+    return taken
+
+
 def take_last_entry():
     """The deferred-check entry of the LAST forward issued by this thread ([ticket, key, policy, overflowed]), or None if that
     forward posted none (exact mode, "verify", a sampled-out view); cleared by the call.  parallel.ViewStreams ties a view to

@@ -450,6 +450,53 @@ std::vector<at::Tensor> rasterize_autograd(const at::Tensor& means3D, const at::
                               scale_modifier, tan_fovx, tan_fovy, H, W, degree, prefiltered, binning_capacity, fused_accumulate);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// One view forward + backward in ONE call, for a caller that knows dL/dcolor before the forward (parallel.ViewStreams.run_view
+// with grad_output: a fixed upstream gradient, a loss formed elsewhere): no autograd node is built and nothing returns to the
+// interpreter between the two halves -- the node, its saved variables and the call of its backward were ~100 us of a view's
+// ~135 us of host time at 1080p, against ~35 us for the ten launches themselves (profiles/r06i_host_profile_dropin.txt).
+// Every differentiable input that requires a gradient must be a LEAF whose .grad exists (contiguous float32, 16-byte
+// aligned): the kernels add into it in place, exactly what the compiled node does under fused gradient accumulation
+// (RasterizeFn::backward above), in the same accumulate chain.  Returns an empty vector -- nothing done -- when an input does
+// not qualify: the caller takes the autograd path.  Otherwise (color, radii, depth, geom) with num_rendered in
+// last_num_rendered(); the images carry no grad_fn.
+// ------------------------------------------------------------------------------------------------------------------
+std::vector<at::Tensor> rasterize_view_step(const at::Tensor& means3D, const at::Tensor& means2D, const at::Tensor& sh,
+                                            const at::Tensor& colors, const at::Tensor& opacities, const at::Tensor& scales,
+                                            const at::Tensor& rotations, const at::Tensor& cov3D, const at::Tensor& bg,
+                                            const at::Tensor& viewmatrix, const at::Tensor& projmatrix, const at::Tensor& campos,
+                                            double scale_modifier, double tan_fovx, double tan_fovy, int64_t H, int64_t W,
+                                            int64_t degree, bool prefiltered, int64_t binning_capacity, const at::Tensor& grad_color)
+{
+    require_device(means3D, "means3D");
+    const c10::Device dev = means3D.device();
+    // order of rasterize_gaussians_backward's accumulate list: means2D, colors, opacity, means3D, cov3D, sh, scales, rotations
+    const at::Tensor* in[8] = { &means2D, &colors, &opacities, &means3D, &cov3D, &sh, &scales, &rotations };
+    std::vector<OptT> acc(8);
+    for (int k = 0; k < 8; k++) {
+        const at::Tensor& t = *in[k];
+        if (!t.defined() || t.numel() == 0 || !t.requires_grad()) continue;          // no gradient wanted: written to a scratch tensor
+        if (!t.is_leaf()) return {};
+        const at::Tensor& g = t.grad();
+        if (!g.defined() || !g.is_contiguous() || g.scalar_type() != at::kFloat || g.device() != dev || g.numel() != t.numel() ||
+            reinterpret_cast<uintptr_t>(g.data_ptr()) % 16 != 0)
+            return {};
+        acc[k] = g;
+    }
+    if (!grad_color.defined() || grad_color.dim() != 3 || grad_color.size(1) != H || grad_color.size(2) != W) return {};
+    at::NoGradGuard no_grad;
+    FwdResult r = rasterize_gaussians(bg, means3D, colors, opacities, scales, rotations, scale_modifier, cov3D, viewmatrix,
+                                      projmatrix, tan_fovx, tan_fovy, H, W, sh, degree, campos, prefiltered, false, binning_capacity);
+    g_last_num_rendered = std::get<0>(r);
+    if (means3D.size(0) != 0) {
+        FusedBackwardScope fused_scope(true);
+        (void)rasterize_gaussians_backward(bg, means3D, std::get<3>(r), colors, scales, rotations, scale_modifier, cov3D, viewmatrix,
+                                           projmatrix, tan_fovx, tan_fovy, grad_color, OptT(), sh, degree, campos, std::get<4>(r),
+                                           std::get<0>(r), std::get<5>(r), std::get<6>(r), false, binning_capacity, acc, true);
+    }
+    return { std::get<1>(r), std::get<3>(r), std::get<2>(r), std::get<4>(r) };
+}
+
 at::Tensor mark_visible(const at::Tensor& means3D, const at::Tensor& viewmatrix, const at::Tensor& projmatrix)
 {
     require_device(means3D, "means3D");
@@ -513,6 +560,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rasterize_autograd", &rasterize_autograd);
     m.def("last_num_rendered", [] { return g_last_num_rendered; });
     m.def("mark_visible", &mark_visible);
+    m.def("rasterize_view_step", &rasterize_view_step);
     m.def("check", &check);
     m.def("header_post", &header_post);
     m.def("request_early_header", [] { lr_request_early_header(); });

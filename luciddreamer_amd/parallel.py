@@ -650,6 +650,7 @@ class ViewStreams:
         self._i = 0
         self._prev_bwd = None
         self._caller = None
+        self.waited_s = 0.0              # total time end_step() spent waiting for the last view's header ("recover")
 
     def begin_step(self):
         from . import _lib, config
@@ -721,9 +722,17 @@ class ViewStreams:
         torch.cuda.set_stream(s)
         try:
             config.take_last_entry()
-            out = forward_fn()
+            # grad_output known up front: the rasterizer call inside forward_fn may run its backward right behind its forward
+            # (one call into the binding, no autograd node -- rasterizer.rasterize_gaussians); if it did, nothing is left to do
+            config.offer_grad_output(grad_output if (grad_output is not None and self.direct) else None)
+            try:
+                out = forward_fn()
+            finally:
+                taken = config.grad_output_taken()
             entry = config.take_last_entry()                 # this view's header entry, if its forward was an async one
-            if backward_fn is not None:
+            if taken:
+                redo = lambda o, g=grad_output: torch.autograd.backward([o], [g])     # (end_step: a lost view, run again)
+            elif backward_fn is not None:
                 if self._prev_bwd is not None:
                     s.wait_event(self._prev_bwd)
                 with _calling_thread_backward():
@@ -776,7 +785,10 @@ class ViewStreams:
                 # The header copies complete when the LAST view's compaction scan has run -- its blend and backward are still
                 # queued behind, so the GPU stays busy while the host looks.  A view whose instance count exceeded its
                 # buffer contributed zero gradients; it is run again here, exact mode, on the caller's stream.
+                import time
+                t0 = time.perf_counter()
                 config.drain()
+                self.waited_s += time.perf_counter() - t0     # host time spent BLOCKED on the last header (not host work)
                 lost = [v for v in views if v[0][3]]
                 if lost:
                     with config.force_exact(), config.overflow_policy("verify"):

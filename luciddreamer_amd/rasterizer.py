@@ -139,6 +139,19 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
     capacity = config.capacity_for(means3D, rs)
     verifying = config.verifying(capacity)
     fused = config.fused_grad_accumulation()
+    offered = config.offered_grad_output()
+    if offered is not None and fused and not verifying:
+        # the caller already holds dL/dcolor (parallel.ViewStreams.run_view): forward and backward in ONE call of the binding,
+        # gradients added into the leaves' .grad by the kernels, no autograd node (csrc/torch_ext.cpp rasterize_view_step).
+        # An input that is not a leaf with a suitable .grad -> empty result -> the autograd path below, offer untouched.
+        out = _C.rasterize_view_step(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
+                                     rs.viewmatrix, rs.projmatrix, rs.campos, rs.scale_modifier, rs.tanfovx, rs.tanfovy,
+                                     rs.image_height, rs.image_width, rs.sh_degree, rs.prefiltered, capacity, offered)
+        if out:
+            color, radii, depth, geom = out
+            config.mark_grad_output_taken()
+            config.note_forward(means3D, rs, _C.last_num_rendered(), geom, capacity)
+            return color, radii, depth
 
     def run(cap):
         return _C.rasterize_autograd(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs.bg,
@@ -229,6 +242,9 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity, s
                                         raster_settings)
 
 
+_EMPTY = torch.Tensor([])           # never written: one instance serves every call (three constructions per call were ~6 us)
+
+
 class GaussianRasterizer(nn.Module):
     def __init__(self, raster_settings):
         super().__init__()
@@ -250,7 +266,7 @@ class GaussianRasterizer(nn.Module):
         if (not scale_rot_complete and cov3D_precomp is None) or (scale_rot_given and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
-        empty = torch.Tensor([])        # the reference's placeholder for an absent optional input
+        empty = _EMPTY                  # the reference's placeholder for an absent optional input (`torch.Tensor([])`, :198-208)
         shs = empty if shs is None else shs
         colors_precomp = empty if colors_precomp is None else colors_precomp
         scales = empty if scales is None else scales

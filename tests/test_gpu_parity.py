@@ -359,6 +359,8 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     g = synthetic.upstream_grad(180, 320).to(hip_device)
     bg = torch.zeros(3, device=hip_device)
 
+    seen_nodes = []
+
     def run(n_streams, grouped=False, direct=True):
         leaf = {k: v.to(hip_device).requires_grad_(True) for k, v in cloud.items()}
         grads = parallel.FlatGrads(list(leaf.values()))
@@ -378,8 +380,11 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
                 m2d.grad.zero_()
                 pipe.begin_step()
                 for r in rast:
-                    fwd = lambda r=r: r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
-                                        shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0]
+                    def fwd(r=r):
+                        out = r(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])[0]
+                        seen_nodes.append((grouped, direct, out.grad_fn is not None))
+                        return out
                     if grouped:                     # three views per pass of the autograd engine (8 views: 3 + 3 + 2)
                         pipe.run_view(fwd, grad_output=g)
                     else:
@@ -401,9 +406,15 @@ def test_two_stream_view_pipeline_equals_sequential(hip_device):
     # the backward node called directly on the issuing thread (no engine): the per-view order, bit for bit the 2-stream result
     assert np.array_equal(f2, f4) or np.abs(f1 - f4).max() <= 1e-5 * np.abs(f1).max()
     assert np.abs(m1 - m4).max() <= 1e-5 * np.abs(m1).max()
+    # ... and that last run took the ONE-CALL path (grad_output known up front, leaves with .grad: forward + backward inside
+    # _C.rasterize_view_step, no autograd node: the returned image has no grad_fn); every other run built nodes
+    assert all(not has_node for grouped, direct, has_node in seen_nodes if grouped and direct)
+    assert all(has_node for grouped, direct, has_node in seen_nodes if not (grouped and direct))
+    assert sum(1 for grouped, direct, _ in seen_nodes if grouped and direct) == 16
 
 
-def test_view_pipeline_recovers_views_that_overflow_their_buffer(hip_device):
+@pytest.mark.parametrize("one_call", [False, True])
+def test_view_pipeline_recovers_views_that_overflow_their_buffer(hip_device, one_call):
     """a ViewStreams step must not lose a view.  The high-water mark is made too small for most views of the
     path (as after a densification, or on a path whose first views are the cheap ones): those views overflow their binning
     buffer, the device-side guard zeroes their gradients, and end_step() runs them again in exact mode -- the step's
@@ -443,7 +454,10 @@ def test_view_pipeline_recovers_views_that_overflow_their_buffer(hip_device):
             pipe = parallel.ViewStreams(hip_device, 2)
             pipe.begin_step()
             for r in rast:
-                pipe.run_view(lambda r=r: fwd(r), lambda col: col.backward(g))
+                if one_call:                     # grad_output up front: forward + backward in one call of the binding; a view
+                    pipe.run_view(lambda r=r: fwd(r), grad_output=g)          # that overflowed is re-run through autograd
+                else:
+                    pipe.run_view(lambda r=r: fwd(r), lambda col: col.backward(g))
             recovered = pipe.end_step()
             torch.cuda.synchronize()
             assert config.current_policy() == "verify"                # the step's temporary policy is gone
