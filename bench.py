@@ -893,7 +893,8 @@ def main():
             "drop_in_host_work_ms_per_step": (entry_points or {}).get("drop_in_host_work_ms_per_step"),
             "sustained_views_per_s": (sustained or {}).get("views_per_s"),
             "c5_train_loop_ms_per_iter": {k: (c5.get(k) or {}).get("ms_per_iter") for k in
-                                          ("this_rasterizer", "this_rasterizer_after_install", "with_optional_pieces",
+                                          ("this_rasterizer", "this_rasterizer_after_install", "this_rasterizer_after_install_fuse_step",
+                                           "with_optional_pieces",
                                            "reference_kernels_on_this_gpu")} if c5 and "error" not in c5 else c5.get("error"),
             "headline_step_parity": None if not hs else {
                 m: {"kernel_shapes": hs[m]["kernel_shapes"], "grad_rows_above_1e-4_worst_tensor": hs[m]["grad_rows_above_1e-4_worst_tensor"],
@@ -1065,6 +1066,11 @@ def run_cpu_baseline(wl):
             for policy, key, what, active in (
                     ("verify", "this_rasterizer_after_install",
                      "the same unchanged loop after luciddreamer_amd.install(reference modules): one call, no edits to the caller", None),
+                    ("verify", "this_rasterizer_after_install_fuse_step",
+                     "the same after install(reference modules, fuse_step=True): the optimizer step of every plain iteration is taken "
+                     "BY its backward pass (the kernel that sums a visible Gaussian's gradient applies Adam to its rows; step() "
+                     "finishes the Gaussians the view did not touch) -- parameters bit-identical to the line above "
+                     "(tests/test_gpu_optim.py, tests/test_gpu_reference_stack.py)", None),
                     ("drop", "this_rasterizer_after_install_policy_drop",
                      "the same with config.set_async(True, on_overflow='drop'): the forward does not wait for its own header (a view "
                      "that needs more than 1.3 x the instances of any view before it is warned about and contributes no gradient)", None),
@@ -1076,7 +1082,8 @@ def run_cpu_baseline(wl):
                 config.set_async(True, on_overflow=policy)
                 for _pass in range(2):
                     with ref_loop.stack("ours") as (R, dev):
-                        handle = luciddreamer_amd.install(R, backward_on_calling_thread=True)    # the single-threaded loop: what "auto" picks there
+                        handle = luciddreamer_amd.install(R, backward_on_calling_thread=True,    # the single-threaded loop: what "auto" picks there
+                                                          fuse_step=key.endswith("_fuse_step"))
                         try:
                             gm = ref_loop.model_from_cloud(R, base, dev, active_sh_degree=active)
                             cams_r, tg_r, dg_r, opt_r = ref_loop.resident(R, gm, dev, cams, targets, depths, iters)

@@ -86,6 +86,9 @@ def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, featur
         binning_capacity, acc))
 
 
+# the raw-mode backward that takes an armed FusedAdam's step for the Gaussians it visits, and the step of the others
+rasterize_gaussians_raw_backward_adam = _C_ext.rasterize_gaussians_raw_backward_adam
+adam_rest_step = _C_ext.adam_rest_step
 mark_visible = _C_ext.mark_visible
 check = _C_ext.check
 # the operator with its autograd node compiled (csrc/torch_ext.cpp RasterizeFn); returns (color, radii, depth, geom), the

@@ -47,13 +47,7 @@ k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps
     const float step_size = T.step_size[t];
     // the same roundings as torch's kernels (which hipcc compiles with FMA contraction): lerp = fma(w, b - a, a),
     // addcmul = fma(value * t1, t2, self), addcdiv = fma(value, t1 / t2, self); mul_, sqrt, div, add are separate
-    auto one = [&](float gi, float& mi, float& vi, float& pi) {
-        mi = __builtin_fmaf(w1, gi - mi, mi);
-        vi = vi * beta2;
-        vi = __builtin_fmaf(w2 * gi, gi, vi);
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = __builtin_fmaf(-step_size, mi / denom, pi);
-    };
+    auto one = [&](float gi, float& mi, float& vi, float& pi) { adam_one(gi, mi, vi, pi, w1, beta2, w2, bc2_sqrt, eps, step_size); };
     // 16 bytes per lane and access (the four arrays are whole allocations: 16-byte aligned); round 3 moved one float per
     // lane and reached 4.6-5.3 TB/s of the 6.29 TB/s this part streams
     const bool wide = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
@@ -83,7 +77,86 @@ k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps
     }
 }
 
+// The step with gradient ZERO for the rows the fused backward did not visit (launch_adam_rest): element e of tensor t belongs
+// to Gaussian e / row_len[t]; a Gaussian with tiles_touched != 0 was stepped by k_gauss_bwd<RAW, ADAM> with its real gradient.
+// An element whose moments are both zero does not move (adam_one(0, 0, 0, p) = p): nothing is read beyond the moments.
+struct AdamRest { AdamFuse a; unsigned long long n[6]; unsigned int row_len[6]; };
+__global__ void __launch_bounds__(256)
+k_adam_rest(AdamRest R, const uint32_t* __restrict__ tiles_touched, const GeomHeader* __restrict__ hdr)
+{
+    const int t = blockIdx.y;
+    float* __restrict__ p = R.a.p[t];
+    float* __restrict__ m = R.a.m[t];
+    float* __restrict__ v = R.a.v[t];
+    const unsigned long long n = R.n[t];
+    if (n == 0 || p == nullptr) return;
+    const unsigned int rl = R.row_len[t];
+    const float step_size = R.a.step_size[t];
+    const bool all = hdr->overflow != 0u;                      // the backward skipped the whole view: every row is "the rest"
+    float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
+    float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
+    float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
+    const unsigned long long n4 = n / 4;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long e0 = 4 * i;
+        const unsigned int g0 = (unsigned int)(e0 / rl), g3 = (unsigned int)((e0 + 3) / rl);
+        bool todo[4];
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned int gk = (g0 == g3) ? g0 : (unsigned int)((e0 + k) / rl);
+            todo[k] = all || tiles_touched[gk] == 0u;
+            any |= todo[k];
+        }
+        if (!any) continue;
+        float4 mi = m4[i], vi = v4[i];
+        float* mf = &mi.x; float* vf = &vi.x;
+        bool live = false;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            todo[k] = todo[k] && (((__float_as_uint(mf[k]) | __float_as_uint(vf[k])) & 0x7fffffffu) != 0u);
+            live |= todo[k];
+        }
+        if (!live) continue;
+        float4 pi = p4[i];
+        float* pf = &pi.x;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (todo[k]) adam_one(0.f, mf[k], vf[k], pf[k], R.a.w1, R.a.beta2, R.a.w2, R.a.bc2_sqrt, R.a.eps, step_size);
+        // (the words of visited Gaussians in the group go back as they were read: the fused backward has finished by now)
+        p4[i] = pi; m4[i] = mi; v4[i] = vi;
+    }
+    for (unsigned long long i = 4 * n4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+        if (!(all || tiles_touched[(unsigned int)(i / rl)] == 0u)) continue;
+        float mi = m[i], vi = v[i];
+        if (((__float_as_uint(mi) | __float_as_uint(vi)) & 0x7fffffffu) == 0u) continue;
+        float pi = p[i];
+        adam_one(0.f, mi, vi, pi, R.a.w1, R.a.beta2, R.a.w2, R.a.bc2_sqrt, R.a.eps, step_size);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
 }  // namespace
+
+void launch_adam_rest(int P, int M, const uint32_t* tiles_touched, const GeomHeader* hdr, const AdamFuse& a, hipStream_t s)
+{
+    if (P <= 0) return;
+    AdamRest R;
+    R.a = a;
+    const unsigned int rows[6] = { 3u, 3u, (unsigned int)(3 * (M - 1)), 1u, 3u, 4u };
+    unsigned long long max_n = 0;
+    for (int t = 0; t < 6; t++) {
+        R.row_len[t] = rows[t] ? rows[t] : 1u;
+        R.n[t] = (unsigned long long)P * rows[t];
+        if (a.p[t] == nullptr) R.n[t] = 0;
+        if (R.n[t] > max_n) max_n = R.n[t];
+    }
+    if (max_n == 0) return;
+    unsigned long long blocks = (max_n / 4 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_adam_rest, dim3((unsigned)blocks, 6), dim3(256), 0, s, R, tiles_touched, hdr);
+}
 
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                 float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,

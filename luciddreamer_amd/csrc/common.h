@@ -438,13 +438,40 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
                        const GaussRec* rec, const float* bg, const float* final_T,
                        const uint32_t* n_contrib, const float* dL_dpix, char* bin_base, const GeomHeader* hdr,
                        const uint32_t* tile_seg0, const float4* c_final, long long seg_bound, hipStream_t s);
+// ---- Adam, element-wise (adam.hip and the step fused into the per-Gaussian backward, gauss_bwd.hip) -----------------------
+// torch's single-tensor Adam (torch/optim/adam.py _single_tensor_adam; no weight decay, amsgrad or maximize) with the roundings
+// of torch's own kernels: lerp = fma(w, b - a, a), addcmul = fma(value * t1, t2, self), addcdiv = fma(value, t1 / t2, self);
+// mul_, sqrt, div, add are separate.  ONE definition: the fused step must give the bits of k_adam on the same gradient.
+//   w1 = 1 - beta1, w2 = 1 - beta2, bc2_sqrt = sqrt(1 - beta2^t), step_size = lr / (1 - beta1^t)
+__device__ __forceinline__ void adam_one(float gi, float& mi, float& vi, float& pi, float w1, float beta2, float w2,
+                                         float bc2_sqrt, float eps, float step_size)
+{
+    mi = __builtin_fmaf(w1, gi - mi, mi);
+    vi = vi * beta2;
+    vi = __builtin_fmaf(w2 * gi, gi, vi);
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    pi = __builtin_fmaf(-step_size, mi / denom, pi);
+}
+// The step of the six stored GaussianModel tensors applied BY the raw-mode backward (lr_backward_raw_adam): tensor order
+// 0 xyz, 1 features_dc, 2 features_rest, 3 opacity, 4 scaling, 5 rotation.  p / m / v: parameters and both moments (updated in
+// place; the parameter pointers are the backward's own inputs).
+struct AdamFuse {
+    float* p[6];
+    float* m[6];
+    float* v[6];
+    float step_size[6];
+    float w1, beta2, w2, bc2_sqrt, eps;
+};
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                       const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,
                       const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      uint32_t accum_mask, float* acc16, hipStream_t s);
+                      uint32_t accum_mask, float* acc16, hipStream_t s, const AdamFuse* adam = nullptr);
+// the same Adam step with gradient zero for the rows of every Gaussian the fused backward did NOT visit (tiles_touched == 0;
+// all rows when the view overflowed its binning buffer and the backward skipped it): adam.hip
+void launch_adam_rest(int P, int M, const uint32_t* tiles_touched, const GeomHeader* hdr, const AdamFuse& a, hipStream_t s);
 // acc16 [P][16]: per-step interleaved accumulator of the five small gradient rows (gauss_bwd.hip); added to the caller's
 // tensors once per step
 void launch_uninterleave_add(int P, const float* acc16, float* mean2D, float* opacity, float* mean3D, float* scale, float* rot,

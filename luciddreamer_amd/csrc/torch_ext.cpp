@@ -338,6 +338,94 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
     return result;
 }
 
+// The raw-mode backward that takes the Adam step of the six stored tensors itself (lr_backward_raw_adam) and the step of the
+// rows it did not visit (lr_adam_rest_step): luciddreamer_amd/optim.py FusedAdam.arm_fused_backward.  Parameters and moments
+// are updated in place; only dL/dmeans2D comes back.  moments: exp_avg then exp_avg_sq, each in the order xyz, features_dc,
+// features_rest, opacity, scaling, rotation.
+namespace {
+struct AdamPack {
+    lr_adam_fusion f;
+    std::vector<at::Tensor> keep;
+};
+void fill_adam(AdamPack& a, const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq,
+               const std::vector<double>& lrs, double beta1, double beta2, double eps, int64_t step, const at::Tensor* params[6])
+{
+    TORCH_CHECK(exp_avg.size() == 6 && exp_avg_sq.size() == 6 && lrs.size() == 6, "six moments / learning rates expected");
+    for (int t = 0; t < 6; t++) {
+        const at::Tensor& p = *params[t];
+        for (const at::Tensor* m : { &exp_avg[t], &exp_avg_sq[t] }) {
+            TORCH_CHECK(m->scalar_type() == at::kFloat && m->is_contiguous() && m->device() == p.device() && m->numel() == p.numel(),
+                        "fused Adam: moments must be contiguous float32 of their parameter's size on its device");
+        }
+        TORCH_CHECK(p.scalar_type() == at::kFloat && p.is_contiguous(), "fused Adam: parameters must be contiguous float32");
+        a.f.exp_avg[t] = p.numel() ? exp_avg[t].data_ptr<float>() : nullptr;
+        a.f.exp_avg_sq[t] = p.numel() ? exp_avg_sq[t].data_ptr<float>() : nullptr;
+        a.f.lr[t] = lrs[t];
+    }
+    a.f.beta1 = beta1; a.f.beta2 = beta2; a.f.eps = eps; a.f.step = static_cast<int>(step);
+}
+}  // namespace
+
+at::Tensor rasterize_gaussians_raw_backward_adam(
+    const at::Tensor& background, const at::Tensor& xyz, const at::Tensor& radii, const at::Tensor& features_dc,
+    const at::Tensor& features_rest, const at::Tensor& opacity_raw, const at::Tensor& scaling_raw, const at::Tensor& rotation_raw,
+    double scale_modifier, const at::Tensor& viewmatrix, const at::Tensor& projmatrix, double tan_fovx, double tan_fovy,
+    const at::Tensor& dL_dout_color, int64_t degree, const at::Tensor& campos, const at::Tensor& geomBuffer, int64_t R,
+    const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug, int64_t binning_capacity,
+    const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq, const std::vector<double>& lrs,
+    double beta1, double beta2, double eps, int64_t step)
+{
+    require_device(xyz, "xyz");
+    const c10::Device dev = xyz.device();
+    const int64_t P = xyz.size(0);
+    const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    at::NoGradGuard no_grad;
+    const int64_t nrest = features_rest.numel() ? features_rest.size(1) : 0;
+    const int M = 1 + static_cast<int>(nrest);
+    at::Tensor g_means2D = at::empty({P, 3}, at::TensorOptions().dtype(at::kFloat).device(dev));
+    if (P == 0) return g_means2D;
+    const at::Tensor* params[6] = { &xyz, &features_dc, &features_rest, &opacity_raw, &scaling_raw, &rotation_raw };
+    AdamPack a;
+    fill_adam(a, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, params);
+    const Arg bg = f32(background, dev, "background"), view = f32(viewmatrix, dev, "viewmatrix"), proj = f32(projmatrix, dev, "projmatrix"),
+              cam = f32(campos, dev, "campos"), gc = f32(dL_dout_color, dev, "dL_dout_color");
+    const at::Tensor radii_c = radii.contiguous();
+    auto fp = [](const at::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
+    const int rc = lr_backward_raw_adam(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
+                                        static_cast<int>(H), fp(xyz), fp(features_dc), fp(features_rest), fp(opacity_raw),
+                                        fp(scaling_raw), static_cast<float>(scale_modifier), fp(rotation_raw), view.p, proj.p, cam.p,
+                                        static_cast<float>(tan_fovx), static_cast<float>(tan_fovy), radii_c.data_ptr<int>(),
+                                        static_cast<char*>(geomBuffer.data_ptr()), static_cast<char*>(binningBuffer.data_ptr()),
+                                        static_cast<char*>(imageBuffer.data_ptr()), gc.p, g_means2D.data_ptr<float>(), &a.f,
+                                        debug ? 1 : 0, static_cast<long long>(binning_capacity),
+                                        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
+    if (rc < 0) raise_for(rc, "rasterize_gaussians_raw_backward_adam");
+    return g_means2D;
+}
+
+void adam_rest_step(const at::Tensor& geomBuffer, const at::Tensor& xyz, const at::Tensor& features_dc, const at::Tensor& features_rest,
+                    const at::Tensor& opacity_raw, const at::Tensor& scaling_raw, const at::Tensor& rotation_raw,
+                    const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq, const std::vector<double>& lrs,
+                    double beta1, double beta2, double eps, int64_t step)
+{
+    require_device(xyz, "xyz");
+    const c10::Device dev = xyz.device();
+    const int64_t P = xyz.size(0);
+    if (P == 0) return;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    at::NoGradGuard no_grad;
+    const int64_t nrest = features_rest.numel() ? features_rest.size(1) : 0;
+    const at::Tensor* params[6] = { &xyz, &features_dc, &features_rest, &opacity_raw, &scaling_raw, &rotation_raw };
+    AdamPack a;
+    fill_adam(a, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, params);
+    auto fp = [](const at::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
+    const int rc = lr_adam_rest_step(static_cast<int>(P), 1 + static_cast<int>(nrest), static_cast<const char*>(geomBuffer.data_ptr()),
+                                     fp(xyz), fp(features_dc), fp(features_rest), fp(opacity_raw), fp(scaling_raw), fp(rotation_raw),
+                                     &a.f, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
+    if (rc < 0) raise_for(rc, "adam_rest_step");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // The autograd node of the drop-in operator in C++ (RAST/depth_diff_gaussian_rasterization_min/__init__.py:44-156 is a
 // Python torch.autograd.Function).  With the Python node a 1080p view cost ~230 us of host time against ~190 us of GPU
@@ -561,6 +649,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("last_num_rendered", [] { return g_last_num_rendered; });
     m.def("mark_visible", &mark_visible);
     m.def("rasterize_view_step", &rasterize_view_step);
+    m.def("rasterize_gaussians_raw_backward_adam", &rasterize_gaussians_raw_backward_adam);
+    m.def("adam_rest_step", &adam_rest_step);
     m.def("check", &check);
     m.def("header_post", &header_post);
     m.def("request_early_header", [] { lr_request_early_header(); });

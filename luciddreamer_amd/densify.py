@@ -239,8 +239,21 @@ def add_densification_stats(model, viewspace_point_tensor, radii):
         _lib.raise_for(rc, "lr_densify_stats")
 
 
+def _no_fused_step_pending(model):
+    """A backward that took the optimizer's step for its visible Gaussians (optim.FusedAdam.arm_fused_backward) must be
+    followed by step() on the SAME parameter set: surgery in between is refused loudly (the reference would have densified on
+    the pre-step parameters and skipped the step: the iteration must not have been armed)."""
+    opt = getattr(model, "optimizer", None)
+    if getattr(opt, "_fused_pending", None) is not None:
+        raise RuntimeError("luciddreamer_amd.densify: the optimizer holds a fused step that step() has not finished; iterations "
+                           "that densify / prune must not be armed (install(fuse_step=True) arms by the reference's schedule)")
+    if hasattr(opt, "disarm"):
+        opt.disarm()
+
+
 def prune_points(model, mask):
     """Remove the Gaussians with mask True (gaussian_model.py:290-304)."""
+    _no_fused_step_pending(model)
     st = _store(model)
     st.compact(~mask.reshape(-1).bool())
     _bind(model, st)
@@ -249,6 +262,7 @@ def prune_points(model, mask):
 def densification_postfix(model, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation):
     """Append explicit new rows (gaussian_model.py:328-346); Adam moments of the new rows are zero, the three
     statistics are reset to zero for ALL rows, as in the reference."""
+    _no_fused_step_pending(model)
     st = _store(model)
     n = int(new_xyz.shape[0])
     start = st.P

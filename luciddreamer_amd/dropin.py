@@ -179,8 +179,26 @@ def _raw_ok(pc, opt, override_color):
     return True
 
 
+def plain_iteration(training_args, iteration) -> bool:
+    """Does iteration `iteration` of the reference's training loop (R/luciddreamer.py:283-327) run `loss.backward()` and
+    `optimizer.step()` back to back on an UNCHANGED parameter set?  False on the iterations that densify / prune (:314-317),
+    reset opacities (:319-322) or skip the step (:325: the last one).  training_args: the GSParams object training_setup got."""
+    a = training_args
+    need = ("iterations", "densify_until_iter", "densify_from_iter", "densification_interval", "opacity_reset_interval")
+    if any(not hasattr(a, k) for k in need):
+        return False
+    if not iteration < a.iterations:
+        return False
+    if iteration < a.densify_until_iter:
+        if iteration > a.densify_from_iter and iteration % a.densification_interval == 0:
+            return False
+        if iteration % a.opacity_reset_interval == 0 or (getattr(a, "white_background", False) and iteration == a.densify_from_iter):
+            return False
+    return True
+
+
 def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=True, losses=True, adam=True, stats=True,
-            densify=True, rebind=True, lazy_filter=True, backward_on_calling_thread="auto"):
+            densify=True, rebind=True, lazy_filter=True, backward_on_calling_thread="auto", fuse_step=False):
     """gaussian_renderer, loss: the reference's modules (or None to leave alone); gaussian_model: its GaussianModel class or
     the module that defines it.  lazy_filter: the visibility filter the replaced render returns keeps the caller's masked
     max-radii update on the device (_VisFilter above); False = a plain bool tensor.  backward_on_calling_thread ("auto": only
@@ -190,7 +208,15 @@ def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=Tr
     short nodes per iteration, every one of them only ENQUEUES work) the hand-off and the two threads' turns at the
     interpreter lock cost more than the nodes -- the unchanged loop at 1 M Gaussians / 512^2 went 2.09 -> 1.28 ms per iteration
     on the same box (profiles/r04q_loop_segments_backward_thread.txt).  A single namespace with attributes `gaussian_renderer`, `loss`, `gaussian_model` (what
-    oracle/ref_python.reference_modules yields) may be passed as the first argument.  Returns a handle for uninstall()."""
+    oracle/ref_python.reference_modules yields) may be passed as the first argument.  Returns a handle for uninstall().
+    fuse_step (opt-in; needs `adam` and `render`): the optimizer step of an iteration is taken BY its backward pass -- the kernel
+    that has just summed a visible Gaussian's gradient applies Adam to its rows instead of storing 236 B of gradient that
+    optimizer.step() would re-read and the next backward would zero-fill again; step() finishes the step for the Gaussians the
+    view did not touch (optim.FusedAdam.arm_fused_backward; same bits as the unfused pair).  Armed per iteration from
+    GaussianModel.update_learning_rate(iteration) -- the first call of every iteration of R/luciddreamer.py:283-327 -- on the
+    iterations that loop runs backward and step() back to back on an unchanged parameter set (plain_iteration() above: not when
+    it densifies, resets opacities or skips the step).  Only for that loop shape; a deviation the library can see (a parameter
+    replaced, a second gradient source) raises in step()."""
     if gaussian_renderer is not None and loss is None and gaussian_model is None and hasattr(gaussian_renderer, "gaussian_renderer"):
         ns = gaussian_renderer
         gaussian_renderer, loss, gaussian_model = ns.gaussian_renderer, getattr(ns, "loss", None), getattr(ns, "gaussian_model", None)
@@ -248,7 +274,22 @@ def install(gaussian_renderer=None, loss=None, gaussian_model=None, *, render=Tr
             if isinstance(opt, torch.optim.Adam) and all(p.is_cuda for g in opt.param_groups for p in g["params"]):
                 groups = [{k: v for k, v in g.items() if k in ("params", "lr", "name")} for g in opt.param_groups]
                 self.optimizer = FusedAdam(groups, lr=opt.defaults["lr"], betas=opt.defaults["betas"], eps=opt.defaults["eps"])
+            self._lr_training_args = training_args            # the loop's schedule: what fuse_step arms by
         h.set(cls, "training_setup", training_setup)
+
+        if fuse_step and render and hasattr(cls, "update_learning_rate"):
+            update_lr = cls.update_learning_rate
+
+            def update_learning_rate(self, iteration):
+                out = update_lr(self, iteration)
+                opt, args = getattr(self, "optimizer", None), getattr(self, "_lr_training_args", None)
+                if isinstance(opt, FusedAdam):
+                    if args is not None and plain_iteration(args, iteration):
+                        opt.arm_fused_backward()
+                    else:
+                        opt.disarm()
+                return out
+            h.set(cls, "update_learning_rate", update_learning_rate)
 
     if cls is not None and stats:
         add = cls.add_densification_stats

@@ -12,12 +12,109 @@ import torch
 
 from . import _lib
 
+# Group names of GaussianModel.training_setup (R/scene/gaussian_model.py:155-162) in the tensor order of lr_backward_raw_adam
+FUSED_ORDER = ("xyz", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+_armed = None                # the FusedAdam whose step the NEXT raw-mode rasterizer backward takes (arm_fused_backward)
+
+
+def take_armed(tensors):
+    """rasterizer._RasterizeGaussiansRaw.backward: the armed optimizer if its six parameters ARE `tensors` (identity, in
+    FUSED_ORDER), else None.  Taking disarms."""
+    global _armed
+    opt, _armed = _armed, None
+    if opt is None:
+        return None
+    params = opt._fused_params()
+    if params is None or len(params) != len(tensors) or any(a is not b for a, b in zip(params, tensors)):
+        return None
+    return opt
+
 
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._fused_pending = None       # (geom buffer, params, step) of a backward that took this step's visited rows
+
+    # ---- the step taken by the backward pass (lr_backward_raw_adam; SURVEY.md 8f-4) ------------------------------------------
+    def _fused_groups(self):
+        by_name = {g.get("name"): g for g in self.param_groups}
+        if any(n not in by_name or len(by_name[n]["params"]) != 1 for n in FUSED_ORDER):
+            return None
+        groups = [by_name[n] for n in FUSED_ORDER]
+        if len({(g["betas"][0], g["betas"][1], g["eps"]) for g in groups}) != 1:
+            return None
+        return groups
+
+    def _fused_params(self):
+        groups = self._fused_groups()
+        return None if groups is None else [g["params"][0] for g in groups]
+
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)         # a host tensor, as torch.optim.Adam keeps it
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        if not torch.is_tensor(st["step"]):                                 # state loaded from an older checkpoint
+            st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+        return st
+
+    def arm_fused_backward(self) -> bool:
+        """The NEXT raw-mode rasterizer backward over exactly this optimizer's six GaussianModel tensors (groups named
+        xyz / f_dc / f_rest / opacity / scaling / rotation, one tensor each) takes this optimizer's step for the Gaussians it
+        visits instead of storing their gradients (lr_backward_raw_adam); the step() that follows finishes it for the rest
+        (lr_adam_rest_step).  Parameters and moments after the pair are bit-identical to backward + step(); param.grad stays
+        None.  For a loop in which EVERY armed backward is followed by exactly one step() with no other gradient source and no
+        change of the parameter set in between (R/luciddreamer.py:296-327 on iterations that neither densify nor reset
+        opacities: luciddreamer_amd.install(..., fuse_step=True) arms from update_learning_rate by that schedule).  Anything
+        else is refused loudly: step() raises if a parameter was replaced or received a .grad while a fused step was pending.
+        Returns False (nothing armed) when the groups do not have that shape."""
+        global _armed
+        if self._fused_pending is not None:
+            raise RuntimeError("FusedAdam.arm_fused_backward: the previous fused backward has not been finished by step()")
+        params = self._fused_params()
+        if params is None or not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params):
+            _armed = None
+            return False
+        _armed = self
+        return True
+
+    def disarm(self):
+        global _armed
+        if _armed is self:
+            _armed = None
+
+    def fused_backward_args(self):
+        """Called by the rasterizer's backward once it has taken this optimizer (take_armed): advances the step counts and returns
+        (exp_avg[6], exp_avg_sq[6], lrs[6], beta1, beta2, eps, step) for lr_backward_raw_adam."""
+        groups = self._fused_groups()
+        states = [self._state_of(g["params"][0]) for g in groups]
+        steps = {int(st["step"].item()) for st in states}
+        if len(steps) != 1:
+            raise RuntimeError("FusedAdam: the six tensors have different step counts; the fused backward needs one")
+        for st in states:
+            st["step"] += 1
+        step = steps.pop() + 1
+        b1, b2 = groups[0]["betas"]
+        return ([st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], [float(g["lr"]) for g in groups],
+                float(b1), float(b2), float(groups[0]["eps"]), step)
+
+    def _finish_fused(self):
+        from . import _C
+        geom, params, args = self._fused_pending
+        self._fused_pending = None
+        now = self._fused_params()
+        if now is None or any(a is not b for a, b in zip(now, params)):
+            raise RuntimeError("FusedAdam.step: the parameter set changed between a fused backward and step() -- the step of the "
+                               "visited Gaussians has already been taken; do not arm iterations that densify / prune / replace tensors")
+        if any(p.grad is not None for p in params):
+            raise RuntimeError("FusedAdam.step: a parameter received a .grad while a fused step was pending (a second backward, or "
+                               "another loss term): its gradient would be lost; do not arm such iterations")
+        with torch.cuda.device(params[0].device):
+            _C.adam_rest_step(geom, *params, *args)
+        return set(id(p) for p in params)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -26,23 +123,19 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
+        self.disarm()                        # an armed backward that never ran (no loss.backward() this iteration)
+        done = self._finish_fused() if self._fused_pending is not None else ()
         # one launch per (betas, eps, step count) combination -- a single one for a GaussianModel
         batches = {}
         for group in self.param_groups:
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or id(p) in done:
                     continue
                 if not p.is_cuda or p.dtype != torch.float32 or p.grad.dtype != torch.float32:
                     raise RuntimeError("FusedAdam needs float32 parameters and gradients on a HIP device")
                 if p.grad.is_sparse:
                     raise RuntimeError("FusedAdam does not support sparse gradients")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)     # a host tensor, as torch.optim.Adam keeps it
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                if not torch.is_tensor(st["step"]):                             # state loaded from an older checkpoint
-                    st["step"] = torch.tensor(float(st["step"]), dtype=torch.float32)
+                st = self._state_of(p)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 if not (p.is_contiguous() and st["exp_avg"].is_contiguous() and st["exp_avg_sq"].is_contiguous()):

@@ -37,6 +37,9 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
     """luciddreamer.py:283-327 with `order[it]` as the camera index.  Returns dict(loss=[...], P=[...])."""
     opt = opt or R.arguments.GSParams()
     opt.iterations = iters + 1                      # the reference skips the optimizer step at the last iteration (:325)
+    # the reference reads its densification schedule from `opt` (:307-317); the harness's arguments go there too, so that what
+    # GaussianModel.training_setup(opt) sees IS the schedule the loop below runs (install(fuse_step=True) arms by it)
+    opt.densify_from_iter, opt.densification_interval = densify_from, densify_every
     render, l1_loss, ssim = R.gaussian_renderer.render, R.loss.l1_loss, R.loss.ssim
     bg = torch.zeros(3, device=device)              # R/arguments.py:14 white_background False
     if gm.optimizer is None:
@@ -66,10 +69,12 @@ def train(R, gm, device, cams, order, targets, depth_targets=None, iters=200, de
         with torch.no_grad():
             gm.max_radii2D[vis] = torch.max(gm.max_radii2D[vis], radii[vis])       # :310-312
             gm.add_densification_stats(vsp, vis)
-            if iteration > densify_from and iteration % densify_every == 0:        # :314-317
+            if iteration < opt.densify_until_iter and iteration > opt.densify_from_iter \
+                    and iteration % opt.densification_interval == 0:               # :307, :314-317
                 gm.densify_and_prune(opt.densify_grad_threshold, 0.005, extent, None)
-            gm.optimizer.step()                                                    # :325-327
-            gm.optimizer.zero_grad(set_to_none=True)
+            if iteration < opt.iterations:                                         # :325-327
+                gm.optimizer.step()
+                gm.optimizer.zero_grad(set_to_none=True)
         # the reference's loop does not read the loss (R/luciddreamer.py:283-327 has no .item()): the values are kept on the
         # device and fetched after the last iteration, so that the harness adds no host <-> device round trip of its own
         losses.append(loss.detach())
@@ -86,6 +91,7 @@ def resident(R, gm, device, cams, targets, depth_targets=None, iters=200, opt=No
     to pass to train()."""
     opt = opt or R.arguments.GSParams()
     opt.iterations = iters + 1
+    opt.densify_from_iter = 10 ** 9                 # (train()'s default: no densification unless the caller asks for it)
     if gm.optimizer is None:
         gm.training_setup(opt)
     out = ([c.to(device) for c in cams], [t.to(device) for t in targets],

@@ -135,3 +135,123 @@ def test_coefficients_above_the_active_sh_degree_stay_untouched_and_equal_torch(
         sa, sb = ref.state[a[k]], fus.state[b[k]]
         assert close(sb["exp_avg"], sa["exp_avg"]) and close(sb["exp_avg_sq"], sa["exp_avg_sq"]), k
     assert float(fus.state[b["f_rest"]]["exp_avg_sq"][:, 3:, :].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The optimizer step taken BY the backward pass (lr_backward_raw_adam + lr_adam_rest_step; optim.FusedAdam.arm_fused_backward)
+# ---------------------------------------------------------------------------------------------------------------------
+def _two_clouds(P, dev, seed=7):
+    from luciddreamer_amd import synthetic
+    from luciddreamer_amd.gaussian_renderer import GaussianCloud
+    c = synthetic.make_cloud(P, "band", seed)
+    mk = lambda: GaussianCloud(c["means3D"].to(dev), c["scales"].to(dev), c["rotations"].to(dev), c["opacities"].to(dev),
+                               c["shs"].to(dev), active_sh_degree=0)
+    return mk(), mk()
+
+
+def _adam_for(cloud):
+    from luciddreamer_amd.optim import FusedAdam
+    named = {"xyz": cloud._xyz, "f_dc": cloud._features_dc, "f_rest": cloud._features_rest, "opacity": cloud._opacity,
+             "scaling": cloud._scaling, "rotation": cloud._rotation}
+    return FusedAdam([{"params": [nn.Parameter(v) if not isinstance(v, nn.Parameter) else v], "lr": LRS[k], "name": k}
+                      for k, v in named.items()], lr=0.0, eps=1e-15)
+
+
+@pytest.mark.parametrize("W,H", [(320, 192), (1280, 720)])
+def test_step_taken_by_the_backward_gives_the_bits_of_backward_plus_step(hip_device, W, H):
+    """Same cloud twice, same views, same upstream gradients.  A: raw-mode backward writes the gradients, FusedAdam.step()
+    applies them (lr_backward_raw + lr_adam_step).  B: the optimizer is armed, the backward's per-Gaussian kernel takes the step
+    for the Gaussians the view touches and step() takes it for the rest with gradient zero (lr_backward_raw_adam +
+    lr_adam_rest_step).  After every iteration all six parameter tensors and both moments must be the SAME BITS, and so must
+    the screen-space gradients the densification statistics read -- over views that see a fraction of the band cloud (most
+    rows are 'the rest'), with the SH degree raised and a learning rate changed on the way, and an un-armed iteration in between."""
+    from luciddreamer_amd import cameras, synthetic
+    from luciddreamer_amd.gaussian_renderer import render_raw
+    P = 40_000
+    a, b = _two_clouds(P, hip_device)
+    for cl in (a, b):
+        for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+            setattr(cl, n, nn.Parameter(getattr(cl, n).detach()))
+    opt_a, opt_b = _adam_for(a), _adam_for(b)
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(W, H, n_views=12)]
+    bg = torch.zeros(3, device=hip_device)
+    gen = torch.Generator().manual_seed(5)
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    visited = []
+    for it in range(10):
+        cam = cams[(5 * it) % 12]
+        if it == 4:
+            a.active_sh_degree = b.active_sh_degree = 2
+        if it == 6:
+            for opt in (opt_a, opt_b):
+                for grp in opt.param_groups:
+                    if grp["name"] == "xyz":
+                        grp["lr"] = 1.0e-4
+        g = torch.randn(3, H, W, generator=gen).to(hip_device)
+        armed = it != 7                                              # one iteration the plain way in the middle of the run
+        pa = render_raw(cam, a, bg_color=bg)
+        (pa["render"] * g).sum().backward()
+        opt_a.step()
+        opt_a.zero_grad(set_to_none=True)
+        if armed:
+            assert opt_b.arm_fused_backward()
+        pb = render_raw(cam, b, bg_color=bg)
+        (pb["render"] * g).sum().backward()
+        if armed:
+            assert all(getattr(b, n).grad is None for n in names) and opt_b._fused_pending is not None
+        else:
+            assert all(getattr(b, n).grad is not None for n in names)
+        opt_b.step()
+        opt_b.zero_grad(set_to_none=True)
+        assert opt_b._fused_pending is None
+        visited.append(float((pb["radii"] > 0).float().mean()))
+        assert torch.equal(pa["viewspace_points"].grad, pb["viewspace_points"].grad), it
+        for n in names:
+            x, y = getattr(a, n), getattr(b, n)
+            assert torch.equal(x, y), (it, n, float((x - y).abs().max()))
+            sa, sb = opt_a.state[x], opt_b.state[y]
+            assert int(sa["step"]) == int(sb["step"]) == it + 1
+            assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), (it, n)
+    assert 0.02 < min(visited) and max(visited) < 0.6, visited      # the views really split the cloud into visited rows and the rest
+    assert float((a._xyz.detach() - _two_clouds(P, hip_device)[0]._xyz.detach()).abs().max()) > 0
+
+
+def test_fused_step_refuses_what_it_cannot_do_exactly(hip_device):
+    """Armed, but ... (i) the parameter set is replaced between backward and step(), (ii) a parameter receives a second gradient:
+    step() raises instead of applying half a step silently; (iii) the backward runs over OTHER tensors than the optimizer's: the
+    offer is simply not taken (plain gradients, plain step); (iv) an armed backward that never ran is forgotten by step()."""
+    from luciddreamer_amd import cameras
+    from luciddreamer_amd.gaussian_renderer import render_raw
+    P, W, H = 5000, 160, 96
+    cam = cameras.rotate360_path(W, H, n_views=4)[1].to(hip_device)
+    g = torch.ones(3, H, W, device=hip_device)
+
+    def fresh():
+        c, other = _two_clouds(P, hip_device, seed=9)
+        for cl in (c, other):
+            for n in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+                setattr(cl, n, nn.Parameter(getattr(cl, n).detach()))
+        return c, other, _adam_for(c)
+    c, other, opt = fresh()
+    assert opt.arm_fused_backward()
+    (render_raw(cam, c)["render"] * g).sum().backward()
+    opt.param_groups[0]["params"][0] = nn.Parameter(c._xyz.detach().clone())       # (i) what a densification does
+    with pytest.raises(RuntimeError, match="parameter set changed"):
+        opt.step()
+    c, other, opt = fresh()
+    assert opt.arm_fused_backward()
+    (render_raw(cam, c)["render"] * g).sum().backward()
+    c._opacity.grad = torch.ones_like(c._opacity)                                    # (ii)
+    with pytest.raises(RuntimeError, match="received a .grad"):
+        opt.step()
+    c, other, opt = fresh()
+    assert opt.arm_fused_backward()
+    (render_raw(cam, other)["render"] * g).sum().backward()                           # (iii) not this optimizer's tensors
+    assert other._xyz.grad is not None and opt._fused_pending is None
+    before = c._xyz.detach().clone()
+    opt.step()                                                                        # nothing to do: c has no gradients
+    assert torch.equal(c._xyz, before)
+    assert opt.arm_fused_backward()                                                   # (iv)
+    opt.step()
+    (render_raw(cam, c)["render"] * g).sum().backward()                               # the stale offer is gone: plain gradients
+    assert c._xyz.grad is not None

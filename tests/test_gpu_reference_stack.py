@@ -132,6 +132,54 @@ def test_install_switches_the_unchanged_loop_onto_the_fused_pieces(hip_device):
     assert abs(a["P_after"] - b["P_after"]) <= max(3, 0.002 * b["P_after"])
 
 
+def test_install_with_the_step_taken_by_the_backward_is_the_same_run(hip_device):
+    """luciddreamer_amd.install(R, fuse_step=True): the UNCHANGED reference loop (tests/ref_loop.py) with the optimizer step
+    of every plain iteration taken by its backward pass (optim.FusedAdam.arm_fused_backward, armed from
+    GaussianModel.update_learning_rate by the loop's own schedule) against the same loop after install(R): the same
+    parameters and Adam moments BIT FOR BIT after 24 iterations with two densifications on the way (iterations 10 and 20 are not
+    armed: the reference densifies on the pre-step parameters there), the same loss curve and the same Gaussian counts.  L1 loss
+    only, so that the two runs are bit-repeatable (ref_loop.train)."""
+    import luciddreamer_amd
+    from luciddreamer_amd import config, optim
+    P, W, H, iters = 20_000, 256, 160, 24
+    cams = cameras.lookaround_path(W, H, n_views=6, max_yaw_deg=25.0, max_pitch_deg=10.0)
+    base, hidden = _perturbed(P, 23)
+    targets, _ = _targets(hidden, cams)
+    order = [int(i) for i in np.random.default_rng(3).integers(0, 6, size=iters)]
+    runs, armed_counts = {}, {}
+    for mode in (False, True):
+        config.reset()
+        config.set_async(True)
+        with ref_loop.stack("ours") as (R, dev):
+            h = luciddreamer_amd.install(R, fuse_step=mode)
+            try:
+                gm = ref_loop.model_from_cloud(R, base, dev)
+                opt = R.arguments.GSParams()
+                opt.lambda_dssim = 0.0
+                opt.percent_dense = 0.0035
+                fused = []
+                out = ref_loop.train(R, gm, dev, cams, order, targets, None, iters=iters, opt=opt, densify_from=5, densify_every=10,
+                                     on_loss=lambda it, gm_, pkg, loss, k: fused.append(optim._armed is gm_.optimizer))
+                assert isinstance(gm.optimizer, optim.FusedAdam)
+                armed_counts[mode] = sum(fused)
+                st = gm.optimizer.state
+                runs[mode] = (out, {n: getattr(gm, n).detach().clone() for n in
+                                    ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")},
+                              {n: (st[getattr(gm, n)]["exp_avg"].clone(), st[getattr(gm, n)]["exp_avg_sq"].clone(),
+                                   int(st[getattr(gm, n)]["step"])) for n in ("_xyz", "_features_rest", "_rotation")})
+            finally:
+                luciddreamer_amd.uninstall(h)
+    config.reset()
+    assert armed_counts == {False: 0, True: iters - 2}, armed_counts         # every iteration but the two that densify
+    (out_a, par_a, st_a), (out_b, par_b, st_b) = runs[False], runs[True]
+    assert np.array_equal(out_a["P"], out_b["P"]) and len(set(out_a["P"])) == 3, out_a["P"]
+    assert np.array_equal(out_a["loss"], out_b["loss"])
+    for n in par_a:
+        assert torch.equal(par_a[n], par_b[n]), n
+    for n in st_a:
+        assert st_a[n][2] == st_b[n][2] and torch.equal(st_a[n][0], st_b[n][0]) and torch.equal(st_a[n][1], st_b[n][1]), n
+
+
 def test_c5_at_size_loss_curve_parity(hip_device):
     """BASELINE.json configs[4] at its stated size: 1 M Gaussians, 512x512, 200 Adam iterations with GSParams learning
     rates (R/arguments.py:19-34) towards fixed RGB + depth targets rendered from a perturbed copy.  Loss = the
