@@ -81,34 +81,36 @@ k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps
 // to Gaussian e / row_len[t]; a Gaussian with tiles_touched != 0 was stepped by k_gauss_bwd<RAW, ADAM> with its real gradient.
 // An element whose moments are both zero does not move (adam_one(0, 0, 0, p) = p): nothing is read beyond the moments.
 struct AdamRest { AdamFuse a; unsigned long long n[6]; unsigned int row_len[6]; };
-__global__ void __launch_bounds__(256)
-k_adam_rest(AdamRest R, const uint32_t* __restrict__ tiles_touched, const GeomHeader* __restrict__ hdr)
+// RL: the tensor's row length as a compile-time constant (1, 3, 4, 45 = the GaussianModel tensors at SH degree 3; 0 = the run-time
+// value): element -> Gaussian is a division per float4 group, and by a run-time divisor it costs more than the group's memory
+// traffic (first version: 154 us for the 20 % of a dense 1 M cloud a view did not touch; round 6).
+template <unsigned int RL>
+__device__ __forceinline__ void adam_rest_tensor(const AdamRest& R, const int t, const uint32_t* __restrict__ tiles_touched, const bool all)
 {
-    const int t = blockIdx.y;
     float* __restrict__ p = R.a.p[t];
     float* __restrict__ m = R.a.m[t];
     float* __restrict__ v = R.a.v[t];
     const unsigned long long n = R.n[t];
-    if (n == 0 || p == nullptr) return;
-    const unsigned int rl = R.row_len[t];
+    const unsigned int rl = RL ? RL : R.row_len[t];
     const float step_size = R.a.step_size[t];
-    const bool all = hdr->overflow != 0u;                      // the backward skipped the whole view: every row is "the rest"
     float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
     float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
     float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
-    const unsigned long long n4 = n / 4;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (unsigned long long)gridDim.x * 256) {
-        const unsigned long long e0 = 4 * i;
-        const unsigned int g0 = (unsigned int)(e0 / rl), g3 = (unsigned int)((e0 + 3) / rl);
+    const unsigned int n4 = (unsigned int)(n / 4);                 // P * row < 2^32 elements (P < 2^24 rows of <= 45 floats: checked by the host)
+    for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const unsigned int e0 = 4u * i;
+        const unsigned int g0 = e0 / rl, g3 = (e0 + 3u) / rl;
         bool todo[4];
-        bool any = false;
+        if (g0 == g3) {
+            const bool td = all || tiles_touched[g0] == 0u;
+            if (!td) continue;
+            todo[0] = todo[1] = todo[2] = todo[3] = true;
+        } else {
+            bool any = false;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned int gk = (g0 == g3) ? g0 : (unsigned int)((e0 + k) / rl);
-            todo[k] = all || tiles_touched[gk] == 0u;
-            any |= todo[k];
+            for (int k = 0; k < 4; k++) { todo[k] = all || tiles_touched[(e0 + k) / rl] == 0u; any |= todo[k]; }
+            if (!any) continue;
         }
-        if (!any) continue;
         float4 mi = m4[i], vi = v4[i];
         float* mf = &mi.x; float* vf = &vi.x;
         bool live = false;
@@ -126,13 +128,27 @@ k_adam_rest(AdamRest R, const uint32_t* __restrict__ tiles_touched, const GeomHe
         // (the words of visited Gaussians in the group go back as they were read: the fused backward has finished by now)
         p4[i] = pi; m4[i] = mi; v4[i] = vi;
     }
-    for (unsigned long long i = 4 * n4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
+    for (unsigned long long i = 4ull * n4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
         if (!(all || tiles_touched[(unsigned int)(i / rl)] == 0u)) continue;
         float mi = m[i], vi = v[i];
         if (((__float_as_uint(mi) | __float_as_uint(vi)) & 0x7fffffffu) == 0u) continue;
         float pi = p[i];
         adam_one(0.f, mi, vi, pi, R.a.w1, R.a.beta2, R.a.w2, R.a.bc2_sqrt, R.a.eps, step_size);
         p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+__global__ void __launch_bounds__(256)
+k_adam_rest(AdamRest R, const uint32_t* __restrict__ tiles_touched, const GeomHeader* __restrict__ hdr)
+{
+    const int t = blockIdx.y;
+    if (R.n[t] == 0 || R.a.p[t] == nullptr) return;
+    const bool all = hdr->overflow != 0u;                      // the backward skipped the whole view: every row is "the rest"
+    switch (R.row_len[t]) {
+        case 1: adam_rest_tensor<1>(R, t, tiles_touched, all); break;
+        case 3: adam_rest_tensor<3>(R, t, tiles_touched, all); break;
+        case 4: adam_rest_tensor<4>(R, t, tiles_touched, all); break;
+        case 45: adam_rest_tensor<45>(R, t, tiles_touched, all); break;
+        default: adam_rest_tensor<0>(R, t, tiles_touched, all); break;
     }
 }
 
