@@ -59,6 +59,8 @@ typedef char* (*lr_alloc_fn)(size_t bytes, void* user);
 #define LR_ACC_SH      (1u << 6)
 #define LR_ACC_SCALE   (1u << 7)
 #define LR_ACC_ROT     (1u << 8)
+/* write-mode outputs: rows of Gaussians without a tile instance stay UNWRITTEN instead of zero-filled (see lr_adam_step_masked) */
+#define LR_ACC_NO_ZERO_FILL (1u << 31)
 
 const char* lr_last_error(void);
 const char* lr_version(void);
@@ -334,36 +336,20 @@ int lr_adam_step(int n_tensors, float* const* params, const float* const* grads,
                  double eps, int step, void* stream);
 
 /*
- * The Adam step of the six stored GaussianModel tensors taken BY the raw-mode backward (the optimizer
- * surgery around the path; R/luciddreamer.py:296-327 runs `loss.backward()` and `optimizer.step()` back to back on every
- * iteration that does not densify).  lr_backward_raw_adam is lr_backward_raw in write mode, except that the gradient rows of
- * xyz / features_dc / features_rest / opacity / scaling / rotation are not stored: the kernel that has just summed a visible
- * Gaussian's gradient applies lr_adam_step's arithmetic to its rows on the spot (same operations element for element: the
- * parameters after the step are bit-identical to lr_backward_raw + lr_adam_step), which saves writing, zero-filling and
- * re-reading 236 B of gradient per Gaussian.  dL_dmean2D [P,3] is still written (the densification statistics read it).
- * lr_adam_rest_step then takes the same step with gradient zero for every Gaussian the backward did not visit (no tile
- * instance in this view -- or every Gaussian, when the view overflowed its binning buffer and the backward skipped it); it
- * needs the geom buffer of the view's forward and must follow lr_backward_raw_adam on the same stream.  Together the two calls
- * are one optimizer step.  The parameter pointers are inputs AND outputs.
- * lr_adam_fusion: exp_avg / exp_avg_sq / lr in the tensor order xyz, features_dc, features_rest, opacity, scaling, rotation
- * (features_rest entries ignored when M == 1); step = the 1-based step count this call is; hyper-parameters as lr_adam_step.
+ * lr_adam_step for gradients that are only VALID in the rows of the Gaussians one view visited (SURVEY.md section 8f-4;
+ * R/luciddreamer.py:296-327 runs `loss.backward()` and `optimizer.step()` back to back, one view per iteration).  A backward
+ * called with LR_ACC_NO_ZERO_FILL in its accumulate_mask writes the gradient rows of the Gaussians that own a tile instance and
+ * leaves every other row of its write-mode outputs UNWRITTEN (dL_dmean2D excepted, which is zero-filled as always: its readers
+ * go by radii > 0); this step takes the gradient of a Gaussian without a tile instance as zero without reading it -- or of every
+ * Gaussian, when the view overflowed its binning buffer and the backward skipped it.  Saved against lr_backward* +
+ * lr_adam_step: the zero-fill pass over the gradient tensors (the reference memsets 300 B per Gaussian per backward,
+ * rasterize_points.cu:154-162) and the read of those zeros.  Same arithmetic element for element: parameters and moments are
+ * bit-identical to the unmasked pair.  geom_buffer: the scratch of the view's forward (its per-Gaussian instance counts are the
+ * mask); every tensor must have P rows, row_len[t] floats each (numel[t] = P * row_len[t]), all arrays 16-byte aligned.
  */
-typedef struct lr_adam_fusion {
-    float* exp_avg[6];
-    float* exp_avg_sq[6];
-    double lr[6];
-    double beta1, beta2, eps;
-    int step;
-} lr_adam_fusion;
-int lr_backward_raw_adam(int P, int D, int M, int R, const float* background, int width, int height,
-                         float* xyz, float* features_dc, float* features_rest, float* opacity_raw,
-                         float* scaling_raw, float scale_modifier, float* rotation_raw,
-                         const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
-                         float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
-                         const float* dL_dpix, float* dL_dmean2D, const lr_adam_fusion* adam, int debug,
-                         long long binning_capacity, void* stream);
-int lr_adam_rest_step(int P, int M, const char* geom_buffer, float* xyz, float* features_dc, float* features_rest,
-                      float* opacity_raw, float* scaling_raw, float* rotation_raw, const lr_adam_fusion* adam, void* stream);
+int lr_adam_step_masked(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const unsigned long long* numel, const unsigned int* row_len, const double* lr,
+                        double beta1, double beta2, double eps, int step, const char* geom_buffer, int P, void* stream);
 
 /*
  * Fused photometric loss of the training loop:

@@ -71,7 +71,7 @@ def rasterize_gaussians_raw(background, xyz, features_dc, features_rest, opacity
 def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, features_rest, opacity_raw, scaling_raw,
                                      rotation_raw, scale_modifier, viewmatrix, projmatrix, tan_fovx, tan_fovy,
                                      dL_dout_color, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug, *,
-                                     binning_capacity=0, accumulate_into=None):
+                                     binning_capacity=0, accumulate_into=None, no_zero_fill=False):
     """Gradients w.r.t. the stored tensors: (means2D, xyz, features_dc, features_rest, opacity, scaling, rotation).
     accumulate_into: {"means2D","xyz","opacity","scaling","rotation": tensor, "features": (dc_grad, rest_grad)} adds
     in place (slot returned as None)."""
@@ -83,12 +83,11 @@ def rasterize_gaussians_raw_backward(background, xyz, radii, features_dc, featur
     return tuple(_C_ext.rasterize_gaussians_raw_backward(
         background, xyz, radii, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw, scale_modifier, viewmatrix,
         projmatrix, tan_fovx, tan_fovy, dL_dout_color, degree, campos, geomBuffer, R, binningBuffer, imageBuffer, debug,
-        binning_capacity, acc))
+        binning_capacity, acc, bool(no_zero_fill)))
 
 
-# the raw-mode backward that takes an armed FusedAdam's step for the Gaussians it visits, and the step of the others
-rasterize_gaussians_raw_backward_adam = _C_ext.rasterize_gaussians_raw_backward_adam
-adam_rest_step = _C_ext.adam_rest_step
+# one Adam step whose gradients are valid only in the rows of the Gaussians one view visited (lr_adam_step_masked)
+adam_step_masked = _C_ext.adam_step_masked
 mark_visible = _C_ext.mark_visible
 check = _C_ext.check
 # the operator with its autograd node compiled (csrc/torch_ext.cpp RasterizeFn); returns (color, radii, depth, geom), the

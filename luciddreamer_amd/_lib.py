@@ -32,8 +32,7 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_take_early_ticket", "lr_forward_ticket", "lr_backward_wait_event", "lr_step_begin", "lr_step_end", "lr_step_abort",
            "lr_views_workspace_bytes", "lr_views_accumulate", "lr_views_check",
            "lr_loss_workspace_bytes", "lr_l1_dssim_forward", "lr_l1_dssim_backward", "lr_l1_dssim_backward_weights",
-           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_densify_stats",
-           "lr_backward_raw_adam", "lr_adam_rest_step",
+           "lr_select_workspace_bytes", "lr_select_rows", "lr_pack_ply_rows", "lr_adam_step", "lr_adam_step_masked", "lr_densify_stats",
            "lr_views_train_workspace_bytes", "lr_views_train_accumulate", "lr_views_train_check")
 
 

@@ -28,9 +28,7 @@ SOURCES = {
     # scalar per-pixel state on purpose (see the kernel): keep the SLP vectoriser from re-packing it
     "render_fwd.hip": ["-fno-slp-vectorize"],
     "render_bwd.hip": ["-fno-slp-vectorize"],
-    # two instantiations of the per-Gaussian backward (gradients stored / Adam step taken on the spot) must produce the SAME
-    # gradient bits: left to -ffp-contract=fast the compiler fuses the same source differently per instantiation
-    "gauss_bwd.hip": ["-ffp-contract=off"],
+    "gauss_bwd.hip": [],
     "knn.hip": [],
     # the separable window sums are long fma chains: packed f32 costs two issue slots plus the moves that form the pairs
     "loss.hip": ["-fno-slp-vectorize"],

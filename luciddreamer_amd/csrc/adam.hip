@@ -77,101 +77,134 @@ k_adam(AdamTensors T, float w1, float beta2, float w2, float bc2_sqrt, float eps
     }
 }
 
-// The step with gradient ZERO for the rows the fused backward did not visit (launch_adam_rest): element e of tensor t belongs
-// to Gaussian e / row_len[t]; a Gaussian with tiles_touched != 0 was stepped by k_gauss_bwd<RAW, ADAM> with its real gradient.
-// An element whose moments are both zero does not move (adam_one(0, 0, 0, p) = p): nothing is read beyond the moments.
-struct AdamRest { AdamFuse a; unsigned long long n[6]; unsigned int row_len[6]; };
-// RL: the tensor's row length as a compile-time constant (1, 3, 4, 45 = the GaussianModel tensors at SH degree 3; 0 = the run-time
-// value): element -> Gaussian is a division per float4 group, and by a run-time divisor it costs more than the group's memory
-// traffic (first version: 154 us for the 20 % of a dense 1 M cloud a view did not touch; round 6).
+// The same step where a Gaussian's gradient rows are only VALID if the view visited it (launch_adam_masked): element e of tensor
+// t belongs to Gaussian e / row_len[t]; tiles_touched == 0 -> gradient zero, the gradient array is not read (the backward left
+// those rows unwritten: no zero-fill pass, no read of zeros -- lr_backward_raw with LR_ACC_NO_ZERO_FILL).  RL: the row length as
+// a compile-time constant (1, 3, 4, 45 = the GaussianModel tensors at SH degree 3; 0 = the run-time value): element -> Gaussian
+// is a division per float4 group, and by a run-time divisor it costs more than the group's memory traffic.
+struct AdamMasked { AdamTensors T; unsigned int row_len[ADAM_MAX_TENSORS]; };
 template <unsigned int RL>
-__device__ __forceinline__ void adam_rest_tensor(const AdamRest& R, const int t, const uint32_t* __restrict__ tiles_touched, const bool all)
+__device__ __forceinline__ void adam_masked_tensor(const AdamMasked& A, const int t, const uint32_t* __restrict__ tiles_touched,
+                                                   const bool none_valid, float w1, float beta2, float w2, float bc2_sqrt, float eps)
 {
-    float* __restrict__ p = R.a.p[t];
-    float* __restrict__ m = R.a.m[t];
-    float* __restrict__ v = R.a.v[t];
-    const unsigned long long n = R.n[t];
-    const unsigned int rl = RL ? RL : R.row_len[t];
-    const float step_size = R.a.step_size[t];
+    float* __restrict__ p = A.T.p[t];
+    const float* __restrict__ g = A.T.g[t];
+    float* __restrict__ m = A.T.m[t];
+    float* __restrict__ v = A.T.v[t];
+    const unsigned long long n = A.T.n[t];
+    const unsigned int rl = RL ? RL : A.row_len[t];
+    const float step_size = A.T.step_size[t];
     float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(g);
     float4* __restrict__ m4 = reinterpret_cast<float4*>(m);
     float4* __restrict__ v4 = reinterpret_cast<float4*>(v);
-    const unsigned int n4 = (unsigned int)(n / 4);                 // P * row < 2^32 elements (P < 2^24 rows of <= 45 floats: checked by the host)
+    const unsigned int n4 = (unsigned int)(n / 4);                 // < 2^32 elements per tensor (checked by the host)
     for (unsigned int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
         const unsigned int e0 = 4u * i;
         const unsigned int g0 = e0 / rl, g3 = (e0 + 3u) / rl;
-        bool todo[4];
+        bool valid[4];
+        bool any_valid;
         if (g0 == g3) {
-            const bool td = all || tiles_touched[g0] == 0u;
-            if (!td) continue;
-            todo[0] = todo[1] = todo[2] = todo[3] = true;
+            any_valid = !none_valid && tiles_touched[g0] != 0u;
+            valid[0] = valid[1] = valid[2] = valid[3] = any_valid;
         } else {
-            bool any = false;
+            any_valid = false;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { todo[k] = all || tiles_touched[(e0 + k) / rl] == 0u; any |= todo[k]; }
-            if (!any) continue;
+            for (int k = 0; k < 4; k++) { valid[k] = !none_valid && tiles_touched[(e0 + k) / rl] != 0u; any_valid |= valid[k]; }
         }
         float4 mi = m4[i], vi = v4[i];
-        float* mf = &mi.x; float* vf = &vi.x;
-        bool live = false;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            todo[k] = todo[k] && (((__float_as_uint(mf[k]) | __float_as_uint(vf[k])) & 0x7fffffffu) != 0u);
-            live |= todo[k];
+        float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any_valid) {
+            gi = g4[i];
+            if (!valid[0]) gi.x = 0.f;
+            if (!valid[1]) gi.y = 0.f;
+            if (!valid[2]) gi.z = 0.f;
+            if (!valid[3]) gi.w = 0.f;
         }
-        if (!live) continue;
+        // all twelve words zero (either sign): nothing to store (as k_adam)
+        const uint32_t any = (__float_as_uint(gi.x) | __float_as_uint(gi.y) | __float_as_uint(gi.z) | __float_as_uint(gi.w) |
+                              __float_as_uint(mi.x) | __float_as_uint(mi.y) | __float_as_uint(mi.z) | __float_as_uint(mi.w) |
+                              __float_as_uint(vi.x) | __float_as_uint(vi.y) | __float_as_uint(vi.z) | __float_as_uint(vi.w)) & 0x7fffffffu;
+        if (any == 0u) continue;
         float4 pi = p4[i];
-        float* pf = &pi.x;
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (todo[k]) adam_one(0.f, mf[k], vf[k], pf[k], R.a.w1, R.a.beta2, R.a.w2, R.a.bc2_sqrt, R.a.eps, step_size);
-        // (the words of visited Gaussians in the group go back as they were read: the fused backward has finished by now)
+        adam_one(gi.x, mi.x, vi.x, pi.x, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam_one(gi.y, mi.y, vi.y, pi.y, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam_one(gi.z, mi.z, vi.z, pi.z, w1, beta2, w2, bc2_sqrt, eps, step_size);
+        adam_one(gi.w, mi.w, vi.w, pi.w, w1, beta2, w2, bc2_sqrt, eps, step_size);
         p4[i] = pi; m4[i] = mi; v4[i] = vi;
     }
     for (unsigned long long i = 4ull * n4 + (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) {
-        if (!(all || tiles_touched[(unsigned int)(i / rl)] == 0u)) continue;
+        const bool ok = !none_valid && tiles_touched[(unsigned int)(i / rl)] != 0u;
         float mi = m[i], vi = v[i];
-        if (((__float_as_uint(mi) | __float_as_uint(vi)) & 0x7fffffffu) == 0u) continue;
+        const float gi = ok ? g[i] : 0.f;
+        if (((__float_as_uint(gi) | __float_as_uint(mi) | __float_as_uint(vi)) & 0x7fffffffu) == 0u) continue;
         float pi = p[i];
-        adam_one(0.f, mi, vi, pi, R.a.w1, R.a.beta2, R.a.w2, R.a.bc2_sqrt, R.a.eps, step_size);
+        adam_one(gi, mi, vi, pi, w1, beta2, w2, bc2_sqrt, eps, step_size);
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
 }
 __global__ void __launch_bounds__(256)
-k_adam_rest(AdamRest R, const uint32_t* __restrict__ tiles_touched, const GeomHeader* __restrict__ hdr)
+k_adam_masked(AdamMasked A, float w1, float beta2, float w2, float bc2_sqrt, float eps, const uint32_t* __restrict__ tiles_touched,
+              const GeomHeader* __restrict__ hdr)
 {
     const int t = blockIdx.y;
-    if (R.n[t] == 0 || R.a.p[t] == nullptr) return;
-    const bool all = hdr->overflow != 0u;                      // the backward skipped the whole view: every row is "the rest"
-    switch (R.row_len[t]) {
-        case 1: adam_rest_tensor<1>(R, t, tiles_touched, all); break;
-        case 3: adam_rest_tensor<3>(R, t, tiles_touched, all); break;
-        case 4: adam_rest_tensor<4>(R, t, tiles_touched, all); break;
-        case 45: adam_rest_tensor<45>(R, t, tiles_touched, all); break;
-        default: adam_rest_tensor<0>(R, t, tiles_touched, all); break;
+    if (t >= A.T.count || A.T.n[t] == 0) return;
+    const bool none_valid = hdr->overflow != 0u;                // the backward skipped the whole view: no row was written
+    switch (A.row_len[t]) {
+        case 1: adam_masked_tensor<1>(A, t, tiles_touched, none_valid, w1, beta2, w2, bc2_sqrt, eps); break;
+        case 3: adam_masked_tensor<3>(A, t, tiles_touched, none_valid, w1, beta2, w2, bc2_sqrt, eps); break;
+        case 4: adam_masked_tensor<4>(A, t, tiles_touched, none_valid, w1, beta2, w2, bc2_sqrt, eps); break;
+        case 45: adam_masked_tensor<45>(A, t, tiles_touched, none_valid, w1, beta2, w2, bc2_sqrt, eps); break;
+        default: adam_masked_tensor<0>(A, t, tiles_touched, none_valid, w1, beta2, w2, bc2_sqrt, eps); break;
     }
 }
 
 }  // namespace
 
-void launch_adam_rest(int P, int M, const uint32_t* tiles_touched, const GeomHeader* hdr, const AdamFuse& a, hipStream_t s)
+static unsigned long long fill_adam_tensors(AdamTensors& T, int n_tensors, float* const* params, const float* const* grads,
+                                            float* const* exp_avg, float* const* exp_avg_sq, const unsigned long long* numel,
+                                            const double* lr, double bc1)
 {
-    if (P <= 0) return;
-    AdamRest R;
-    R.a = a;
-    const unsigned int rows[6] = { 3u, 3u, (unsigned int)(3 * (M - 1)), 1u, 3u, 4u };
+    T.count = n_tensors;
     unsigned long long max_n = 0;
-    for (int t = 0; t < 6; t++) {
-        R.row_len[t] = rows[t] ? rows[t] : 1u;
-        R.n[t] = (unsigned long long)P * rows[t];
-        if (a.p[t] == nullptr) R.n[t] = 0;
-        if (R.n[t] > max_n) max_n = R.n[t];
+    for (int t = 0; t < ADAM_MAX_TENSORS; t++) {
+        const bool on = t < n_tensors;
+        T.p[t] = on ? params[t] : nullptr; T.g[t] = on ? grads[t] : nullptr;
+        T.m[t] = on ? exp_avg[t] : nullptr; T.v[t] = on ? exp_avg_sq[t] : nullptr;
+        T.n[t] = on ? numel[t] : 0;
+        T.step_size[t] = on ? (float)(lr[t] / bc1) : 0.f;
+        if (on && numel[t] > max_n) max_n = numel[t];
     }
-    if (max_n == 0) return;
+    return max_n;
+}
+
+int launch_adam_masked(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const unsigned long long* numel, const unsigned int* row_len, const double* lr,
+                       double beta1, double beta2, double eps, int step, const uint32_t* tiles_touched, const GeomHeader* hdr,
+                       hipStream_t s)
+{
+    if (n_tensors > ADAM_MAX_TENSORS) return -1;
+    AdamMasked A;
+    const double bc1 = 1.0 - std::pow(beta1, (double)step);
+    const double bc2 = 1.0 - std::pow(beta2, (double)step);
+    const unsigned long long max_n = fill_adam_tensors(A.T, n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, bc1);
+    for (int t = 0; t < ADAM_MAX_TENSORS; t++) {
+        A.row_len[t] = (t < n_tensors && row_len[t] > 0) ? row_len[t] : 1u;
+        if (t < n_tensors) {
+            if (numel[t] >= (1ull << 32)) return -2;
+            // 16-byte accesses on all four arrays (whole torch allocations are; a view at an odd offset is refused)
+            if ((reinterpret_cast<uintptr_t>(params[t]) | reinterpret_cast<uintptr_t>(grads[t]) | reinterpret_cast<uintptr_t>(exp_avg[t]) |
+                 reinterpret_cast<uintptr_t>(exp_avg_sq[t])) & 15u)
+                return -3;
+        }
+    }
+    if (max_n == 0) return 0;
     unsigned long long blocks = (max_n / 4 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_adam_rest, dim3((unsigned)blocks, 6), dim3(256), 0, s, R, tiles_touched, hdr);
+    hipLaunchKernelGGL(k_adam_masked, dim3((unsigned)blocks, n_tensors), dim3(256), 0, s, A, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)std::sqrt(bc2), (float)eps, tiles_touched, hdr);
+    return 0;
 }
 
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,

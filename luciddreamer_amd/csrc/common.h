@@ -452,26 +452,13 @@ __device__ __forceinline__ void adam_one(float gi, float& mi, float& vi, float& 
     const float denom = sqrtf(vi) / bc2_sqrt + eps;
     pi = __builtin_fmaf(-step_size, mi / denom, pi);
 }
-// The step of the six stored GaussianModel tensors applied BY the raw-mode backward (lr_backward_raw_adam): tensor order
-// 0 xyz, 1 features_dc, 2 features_rest, 3 opacity, 4 scaling, 5 rotation.  p / m / v: parameters and both moments (updated in
-// place; the parameter pointers are the backward's own inputs).
-struct AdamFuse {
-    float* p[6];
-    float* m[6];
-    float* v[6];
-    float step_size[6];
-    float w1, beta2, w2, bc2_sqrt, eps;
-};
 void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* scales, const float* rotations,
                       const float* shs, const float* cov3D_precomp, const float* colors_precomp,
                       const uint32_t* vis_list, const uint8_t* clamped, const uint32_t* offsets,
                       const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      uint32_t accum_mask, float* acc16, hipStream_t s, const AdamFuse* adam = nullptr);
-// the same Adam step with gradient zero for the rows of every Gaussian the fused backward did NOT visit (tiles_touched == 0;
-// all rows when the view overflowed its binning buffer and the backward skipped it): adam.hip
-void launch_adam_rest(int P, int M, const uint32_t* tiles_touched, const GeomHeader* hdr, const AdamFuse& a, hipStream_t s);
+                      uint32_t accum_mask, float* acc16, hipStream_t s);
 // acc16 [P][16]: per-step interleaved accumulator of the five small gradient rows (gauss_bwd.hip); added to the caller's
 // tensors once per step
 void launch_uninterleave_add(int P, const float* acc16, float* mean2D, float* opacity, float* mean3D, float* scale, float* rot,
@@ -488,6 +475,13 @@ void launch_densify_stats(int P, const int* radii, const float* dL_dmean2D, floa
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                 float* const* exp_avg_sq, const unsigned long long* numel, const double* lr, double beta1, double beta2,
                 double eps, int step, hipStream_t s);
+// ... where the gradient of a Gaussian's rows is only VALID if the view visited it (tiles_touched != 0: lr_backward_raw with
+// LR_ACC_NO_ZERO_FILL left the other rows unwritten) and is taken as zero otherwise -- or for every row, when the view
+// overflowed its binning buffer and the backward skipped it.  row_len[t]: floats per Gaussian of tensor t.
+int launch_adam_masked(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const unsigned long long* numel, const unsigned int* row_len, const double* lr,
+                       double beta1, double beta2, double eps, int step, const uint32_t* tiles_touched, const GeomHeader* hdr,
+                       hipStream_t s);
 // fused L1 + DSSIM loss (loss.hip)
 size_t loss_workspace_bytes(int C, int H, int W);
 // defer_final: leave {loss, l1, ssim} to the launch_loss_backward(..., final_out3) that follows on the same stream

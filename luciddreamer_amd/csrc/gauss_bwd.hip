@@ -116,10 +116,7 @@ __device__ __forceinline__ float row_sum(float v)
 // Gaussian by the caller, which passes the resulting dL/d(view direction) in `dL_ddir` when `have_sh`).
 // RAW (lr_backward_raw) is a template parameter, not a run-time branch: with `if (vp.raw)` blocks in this function
 // ROCm 7.2 hipcc produced wrong dL/dcov3D in the NON-raw path (verified on hardware by removing either block).
-// ADAM (raw mode, write mode): instead of storing the gradient rows of the five stored tensors handled here, the Adam step of
-// those rows is taken on the spot (common.h AdamFuse / adam_one: the bits k_adam produces from the stored gradient); dL/dmean2D
-// is still written -- the caller's densification statistics read it (R/scene/gaussian_model.py:405-407).
-template <bool RAW, bool ADAM>
+template <bool RAW>
 __device__ __forceinline__ void
 gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const bool have_sh, const V3 dL_ddir,
@@ -127,7 +124,7 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-            uint32_t accum_mask, float* __restrict__ acc16, const AdamFuse& ad)
+            uint32_t accum_mask, float* __restrict__ acc16)
 {
     const size_t i = (size_t)idx;
     const float* __restrict__ V = vp.view;
@@ -294,25 +291,6 @@ gauss_backward_one(const int idx, const ViewParams& vp, const float* __restrict_
         }
     }
 
-    if (ADAM) {
-        dL_dmean2D[3 * i] = o_m2d[0]; dL_dmean2D[3 * i + 1] = o_m2d[1]; dL_dmean2D[3 * i + 2] = 0.f;
-        // one element: skipped when gradient and both moments are zero (the step is the identity then, adam.hip)
-        auto step = [&](const int t, const size_t e, const float g) {
-            float m = ad.m[t][e], v = ad.v[t][e];
-            if (((__float_as_uint(g) | __float_as_uint(m) | __float_as_uint(v)) & 0x7fffffffu) == 0u) return;
-            float p = ad.p[t][e];
-            adam_one(g, m, v, p, ad.w1, ad.beta2, ad.w2, ad.bc2_sqrt, ad.eps, ad.step_size[t]);
-            ad.p[t][e] = p; ad.m[t][e] = m; ad.v[t][e] = v;
-        };
-        step(3, i, o_op);
-#pragma unroll
-        for (int k = 0; k < 3; k++) step(0, 3 * i + k, o_m3d[k]);
-#pragma unroll
-        for (int k = 0; k < 3; k++) step(4, 3 * i + k, o_scale[k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) step(5, 4 * i + k, o_rot[k]);
-        return;
-    }
     // ---- interleaved accumulation (lr_views_accumulate): the five small rows of a Gaussian -- mean2D (2 of 3 floats),
     // opacity, mean3D, scale, rotation: 13 floats scattered over five arrays, each a 12-16 byte read-modify-write that
     // moves a 32-byte sector both ways -- live in ONE 64-byte row of acc16 [P][16] during the step: one full line in, one
@@ -374,7 +352,7 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <bool RAW, bool ADAM = false>
+template <bool RAW>
 __global__ void __launch_bounds__(GB_THREADS) __attribute__((amdgpu_waves_per_eu(LR_GB_WAVES, 8)))
 k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __restrict__ scales,
             const float* __restrict__ rotations, const float* __restrict__ shs,
@@ -384,7 +362,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
             float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D, float* __restrict__ dL_dcov3D,
             float* __restrict__ dL_dsh, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-            uint32_t accum_mask, float* __restrict__ acc16, const AdamFuse ad)
+            uint32_t accum_mask, float* __restrict__ acc16)
 {
     constexpr uint32_t SERIAL_MAX = 24;      // instances summed by the owning lane; more -> whole wave helps
     constexpr int BST = 17;                  // LDS row stride (floats) of the per-Gaussian basis rows: odd -> no conflicts
@@ -451,7 +429,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
         // derivatives of ITS Gaussian into LDS, and then 16 LANES share one Gaussian, lane k owning coefficient k:
         // a wave reads/updates 4 complete rows per step with fully used cache lines.
         V3 dL_ddir = { 0.f, 0.f, 0.f };
-        const bool have_sh = shs != nullptr && (ADAM || dL_dsh != nullptr);
+        const bool have_sh = shs != nullptr && dL_dsh != nullptr;
         if (have_sh) {
             const int k = lane & 15, sub = lane >> 4;
             const int K = (vp.D + 1) * (vp.D + 1);
@@ -516,33 +494,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                         const int gs = onv[q] ? g : 0, gls = onv[q] ? gl : 0, ks = onv[q] ? k : 0;
                         const float r0 = s_rgb[0][gs], r1 = s_rgb[1][gs], r2 = s_rgb[2][gs];
                         const float bk = s_b[0][gls * BST + ks];
-                        if (ADAM) {
-                            // every coefficient row of a visited Gaussian is stepped: rows of the active degree with the gradient
-                            // the store below would have written, rows above it with gradient zero (they only move if a moment
-                            // is non-zero: a degree that was lowered again)
-                            const bool onA = g < n_here && k < vp.M;
-                            if (onA) {
-                                const int tsr = (k == 0) ? 1 : 2;
-                                const size_t row = (k == 0) ? (size_t)s_idx[g] * 3 : (size_t)s_idx[g] * (shrow - 3) + 3 * (size_t)(k - 1);
-                                const float gg[3] = { onv[q] ? dv[q][0] + bk * r0 : 0.f, onv[q] ? dv[q][1] + bk * r1 : 0.f,
-                                                      onv[q] ? dv[q][2] + bk * r2 : 0.f };
-                                float mm[3], vv[3];
-                                uint32_t any = 0u;
-#pragma unroll
-                                for (int c = 0; c < 3; c++) {
-                                    mm[c] = ad.m[tsr][row + c]; vv[c] = ad.v[tsr][row + c];
-                                    any |= __float_as_uint(gg[c]) | __float_as_uint(mm[c]) | __float_as_uint(vv[c]);
-                                }
-                                if ((any & 0x7fffffffu) != 0u) {
-#pragma unroll
-                                    for (int c = 0; c < 3; c++) {
-                                        float pp = onv[q] ? sv[q][c] : ad.p[tsr][row + c];
-                                        adam_one(gg[c], mm[c], vv[c], pp, ad.w1, ad.beta2, ad.w2, ad.bc2_sqrt, ad.eps, ad.step_size[tsr]);
-                                        ad.p[tsr][row + c] = pp; ad.m[tsr][row + c] = mm[c]; ad.v[tsr][row + c] = vv[c];
-                                    }
-                                }
-                            }
-                        } else if (onv[q]) {
+                        if (onv[q]) {
                             float* dp = ((RAW && k != 0) ? vp.dL_dsh_rest : dL_dsh) + rowv[q];   // onv[q] holds here
                             dp[0] = dv[q][0] + bk * r0; dp[1] = dv[q][1] + bk * r1; dp[2] = dv[q][2] + bk * r2;
                         }
@@ -558,9 +510,9 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             if (live) dL_ddir = { s_ddir[0][lane], s_ddir[1][lane], s_ddir[2][lane] };
         }
         if (live)
-            gauss_backward_one<RAW, ADAM>(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
+            gauss_backward_one<RAW>(idx, vp, means3D, scales, rotations, have_sh, dL_ddir, cov3D_precomp, g0, g1, g2,
                                dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dscale,
-                               dL_drot, accum_mask, acc16, ad);
+                               dL_drot, accum_mask, acc16);
         lds_barrier();                     // the LDS planes are rewritten by the next round
     }
 }
@@ -619,24 +571,19 @@ void launch_gauss_bwd(const ViewParams& vp, const float* means3D, const float* s
                       const char* bin_base, const GeomHeader* hdr,
                       float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
                       float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
-                      uint32_t accum_mask, float* acc16, hipStream_t s, const AdamFuse* adam)
+                      uint32_t accum_mask, float* acc16, hipStream_t s)
 {
     (void)colors_precomp;
     if (vp.P <= 0) return;
     const int groups = std::min((vp.P + GB_THREADS - 1) / GB_THREADS, GB_MAX_GROUPS);
-    static const AdamFuse none = {};
-    if (vp.raw && adam != nullptr)
-        hipLaunchKernelGGL((k_gauss_bwd<true, true>), dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
+    if (vp.raw)
+        hipLaunchKernelGGL(k_gauss_bwd<true>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
                            cov3D_precomp, vis_list, clamped, offsets, bin_base, hdr, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, nullptr, *adam);
-    else if (vp.raw)
-        hipLaunchKernelGGL((k_gauss_bwd<true>), dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
-                           cov3D_precomp, vis_list, clamped, offsets, bin_base, hdr, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16, none);
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
     else
-        hipLaunchKernelGGL((k_gauss_bwd<false>), dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
+        hipLaunchKernelGGL(k_gauss_bwd<false>, dim3(groups), dim3(GB_THREADS), 0, s, vp, means3D, scales, rotations, shs,
                            cov3D_precomp, vis_list, clamped, offsets, bin_base, hdr, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16, none);
+                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, accum_mask, acc16);
 }
 
 namespace {

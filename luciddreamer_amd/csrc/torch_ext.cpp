@@ -278,7 +278,7 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
     double scale_modifier, const at::Tensor& viewmatrix, const at::Tensor& projmatrix, double tan_fovx, double tan_fovy,
     const at::Tensor& dL_dout_color, int64_t degree, const at::Tensor& campos, const at::Tensor& geomBuffer, int64_t R,
     const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug, int64_t binning_capacity,
-    const std::vector<OptT>& accumulate)
+    const std::vector<OptT>& accumulate, bool no_zero_fill)
 {
     require_device(xyz, "xyz");
     const c10::Device dev = xyz.device();
@@ -317,6 +317,9 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
         }
         ptr[k] = out[k].numel() ? out[k].data_ptr<float>() : nullptr;
     }
+    // no_zero_fill: rows of Gaussians the view did not visit stay unwritten in the write-mode outputs (means2D excepted): for the
+    // masked optimizer step (adam_step_masked below), which does not read them
+    if (no_zero_fill) mask |= LR_ACC_NO_ZERO_FILL;
     if (P != 0) {
         const Arg bg = f32(background, dev, "background"), x = f32(xyz, dev, "xyz"), dc = f32(features_dc, dev, "features_dc"),
                   op = f32(opacity_raw, dev, "opacity"), sc = f32(scaling_raw, dev, "scaling"), rot = f32(rotation_raw, dev, "rotation"),
@@ -324,7 +327,7 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
                   gc = f32(dL_dout_color, dev, "dL_dout_color");
         const at::Tensor radii_c = radii.contiguous();
         hipStream_t cur = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream();
-        ChainScope chain(mask != 0, dev.index(), cur);
+        ChainScope chain((mask & ~LR_ACC_NO_ZERO_FILL) != 0, dev.index(), cur);
         const int rc = lr_backward_raw(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
                                        static_cast<int>(H), x.p, dc.p, rest.p, op.p, sc.p, static_cast<float>(scale_modifier), rot.p,
                                        view.p, proj.p, cam.p, static_cast<float>(tan_fovx), static_cast<float>(tan_fovy),
@@ -338,92 +341,49 @@ std::vector<OptT> rasterize_gaussians_raw_backward(
     return result;
 }
 
-// The raw-mode backward that takes the Adam step of the six stored tensors itself (lr_backward_raw_adam) and the step of the
-// rows it did not visit (lr_adam_rest_step): luciddreamer_amd/optim.py FusedAdam.arm_fused_backward.  Parameters and moments
-// are updated in place; only dL/dmeans2D comes back.  moments: exp_avg then exp_avg_sq, each in the order xyz, features_dc,
-// features_rest, opacity, scaling, rotation.
-namespace {
-struct AdamPack {
-    lr_adam_fusion f;
-    std::vector<at::Tensor> keep;
-};
-void fill_adam(AdamPack& a, const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq,
-               const std::vector<double>& lrs, double beta1, double beta2, double eps, int64_t step, const at::Tensor* params[6])
+// lr_adam_step_masked: one Adam step over tensors with P rows each whose gradients are only valid in the rows of the Gaussians
+// the view of `geomBuffer` visited (a raw-mode backward with no_zero_fill); luciddreamer_amd/optim.py FusedAdam
+void adam_step_masked(const std::vector<at::Tensor>& params, const std::vector<at::Tensor>& grads,
+                      const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq,
+                      const std::vector<double>& lrs, double beta1, double beta2, double eps, int64_t step,
+                      const at::Tensor& geomBuffer)
 {
-    TORCH_CHECK(exp_avg.size() == 6 && exp_avg_sq.size() == 6 && lrs.size() == 6, "six moments / learning rates expected");
-    for (int t = 0; t < 6; t++) {
-        const at::Tensor& p = *params[t];
-        for (const at::Tensor* m : { &exp_avg[t], &exp_avg_sq[t] }) {
-            TORCH_CHECK(m->scalar_type() == at::kFloat && m->is_contiguous() && m->device() == p.device() && m->numel() == p.numel(),
-                        "fused Adam: moments must be contiguous float32 of their parameter's size on its device");
-        }
-        TORCH_CHECK(p.scalar_type() == at::kFloat && p.is_contiguous(), "fused Adam: parameters must be contiguous float32");
-        a.f.exp_avg[t] = p.numel() ? exp_avg[t].data_ptr<float>() : nullptr;
-        a.f.exp_avg_sq[t] = p.numel() ? exp_avg_sq[t].data_ptr<float>() : nullptr;
-        a.f.lr[t] = lrs[t];
+    const size_t n = params.size();
+    TORCH_CHECK(n >= 1 && n <= 16 && grads.size() == n && exp_avg.size() == n && exp_avg_sq.size() == n && lrs.size() == n,
+                "adam_step_masked: 1..16 tensors with one gradient, two moments and one learning rate each");
+    require_device(params[0], "params");
+    const c10::Device dev = params[0].device();
+    const int64_t P = params[0].size(0);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
+    at::NoGradGuard no_grad;
+    std::vector<float*> p(n), m(n), v(n);
+    std::vector<const float*> g(n);
+    std::vector<unsigned long long> numel(n);
+    std::vector<unsigned int> row(n);
+    for (size_t t = 0; t < n; t++) {
+        for (const at::Tensor* x : { &params[t], &grads[t], &exp_avg[t], &exp_avg_sq[t] })
+            TORCH_CHECK(x->scalar_type() == at::kFloat && x->is_contiguous() && x->device() == dev && x->numel() == params[t].numel(),
+                        "adam_step_masked: contiguous float32 tensors of the parameter's size on its device");
+        TORCH_CHECK(params[t].dim() >= 1 && params[t].size(0) == P, "adam_step_masked: every tensor has one row per Gaussian");
+        numel[t] = static_cast<unsigned long long>(params[t].numel());
+        row[t] = P ? static_cast<unsigned int>(params[t].numel() / P) : 1u;
+        p[t] = numel[t] ? params[t].data_ptr<float>() : nullptr;
+        g[t] = numel[t] ? grads[t].data_ptr<float>() : nullptr;
+        m[t] = numel[t] ? exp_avg[t].data_ptr<float>() : nullptr;
+        v[t] = numel[t] ? exp_avg_sq[t].data_ptr<float>() : nullptr;
     }
-    a.f.beta1 = beta1; a.f.beta2 = beta2; a.f.eps = eps; a.f.step = static_cast<int>(step);
-}
-}  // namespace
-
-at::Tensor rasterize_gaussians_raw_backward_adam(
-    const at::Tensor& background, const at::Tensor& xyz, const at::Tensor& radii, const at::Tensor& features_dc,
-    const at::Tensor& features_rest, const at::Tensor& opacity_raw, const at::Tensor& scaling_raw, const at::Tensor& rotation_raw,
-    double scale_modifier, const at::Tensor& viewmatrix, const at::Tensor& projmatrix, double tan_fovx, double tan_fovy,
-    const at::Tensor& dL_dout_color, int64_t degree, const at::Tensor& campos, const at::Tensor& geomBuffer, int64_t R,
-    const at::Tensor& binningBuffer, const at::Tensor& imageBuffer, bool debug, int64_t binning_capacity,
-    const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq, const std::vector<double>& lrs,
-    double beta1, double beta2, double eps, int64_t step)
-{
-    require_device(xyz, "xyz");
-    const c10::Device dev = xyz.device();
-    const int64_t P = xyz.size(0);
-    const int64_t H = dL_dout_color.size(1), W = dL_dout_color.size(2);
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
-    at::NoGradGuard no_grad;
-    const int64_t nrest = features_rest.numel() ? features_rest.size(1) : 0;
-    const int M = 1 + static_cast<int>(nrest);
-    at::Tensor g_means2D = at::empty({P, 3}, at::TensorOptions().dtype(at::kFloat).device(dev));
-    if (P == 0) return g_means2D;
-    const at::Tensor* params[6] = { &xyz, &features_dc, &features_rest, &opacity_raw, &scaling_raw, &rotation_raw };
-    AdamPack a;
-    fill_adam(a, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, params);
-    const Arg bg = f32(background, dev, "background"), view = f32(viewmatrix, dev, "viewmatrix"), proj = f32(projmatrix, dev, "projmatrix"),
-              cam = f32(campos, dev, "campos"), gc = f32(dL_dout_color, dev, "dL_dout_color");
-    const at::Tensor radii_c = radii.contiguous();
-    auto fp = [](const at::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
-    const int rc = lr_backward_raw_adam(static_cast<int>(P), static_cast<int>(degree), M, static_cast<int>(R), bg.p, static_cast<int>(W),
-                                        static_cast<int>(H), fp(xyz), fp(features_dc), fp(features_rest), fp(opacity_raw),
-                                        fp(scaling_raw), static_cast<float>(scale_modifier), fp(rotation_raw), view.p, proj.p, cam.p,
-                                        static_cast<float>(tan_fovx), static_cast<float>(tan_fovy), radii_c.data_ptr<int>(),
-                                        static_cast<char*>(geomBuffer.data_ptr()), static_cast<char*>(binningBuffer.data_ptr()),
-                                        static_cast<char*>(imageBuffer.data_ptr()), gc.p, g_means2D.data_ptr<float>(), &a.f,
-                                        debug ? 1 : 0, static_cast<long long>(binning_capacity),
-                                        c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
-    if (rc < 0) raise_for(rc, "rasterize_gaussians_raw_backward_adam");
-    return g_means2D;
-}
-
-void adam_rest_step(const at::Tensor& geomBuffer, const at::Tensor& xyz, const at::Tensor& features_dc, const at::Tensor& features_rest,
-                    const at::Tensor& opacity_raw, const at::Tensor& scaling_raw, const at::Tensor& rotation_raw,
-                    const std::vector<at::Tensor>& exp_avg, const std::vector<at::Tensor>& exp_avg_sq, const std::vector<double>& lrs,
-                    double beta1, double beta2, double eps, int64_t step)
-{
-    require_device(xyz, "xyz");
-    const c10::Device dev = xyz.device();
-    const int64_t P = xyz.size(0);
-    if (P == 0) return;
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(dev);
-    at::NoGradGuard no_grad;
-    const int64_t nrest = features_rest.numel() ? features_rest.size(1) : 0;
-    const at::Tensor* params[6] = { &xyz, &features_dc, &features_rest, &opacity_raw, &scaling_raw, &rotation_raw };
-    AdamPack a;
-    fill_adam(a, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, params);
-    auto fp = [](const at::Tensor& t) { return t.numel() ? t.data_ptr<float>() : nullptr; };
-    const int rc = lr_adam_rest_step(static_cast<int>(P), 1 + static_cast<int>(nrest), static_cast<const char*>(geomBuffer.data_ptr()),
-                                     fp(xyz), fp(features_dc), fp(features_rest), fp(opacity_raw), fp(scaling_raw), fp(rotation_raw),
-                                     &a.f, c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
-    if (rc < 0) raise_for(rc, "adam_rest_step");
+    // tensors without elements (features_rest at M = 1) are left out
+    std::vector<float*> p2, m2, v2; std::vector<const float*> g2; std::vector<unsigned long long> n2; std::vector<unsigned int> r2;
+    std::vector<double> l2;
+    for (size_t t = 0; t < n; t++)
+        if (numel[t]) { p2.push_back(p[t]); g2.push_back(g[t]); m2.push_back(m[t]); v2.push_back(v[t]); n2.push_back(numel[t]);
+                        r2.push_back(row[t]); l2.push_back(lrs[t]); }
+    if (p2.empty() || P == 0) return;
+    const int rc = lr_adam_step_masked(static_cast<int>(p2.size()), p2.data(), g2.data(), m2.data(), v2.data(), n2.data(), r2.data(),
+                                       l2.data(), beta1, beta2, eps, static_cast<int>(step),
+                                       static_cast<const char*>(geomBuffer.data_ptr()), static_cast<int>(P),
+                                       c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(dev.index()).stream());
+    if (rc < 0) raise_for(rc, "adam_step_masked");
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -649,8 +609,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("last_num_rendered", [] { return g_last_num_rendered; });
     m.def("mark_visible", &mark_visible);
     m.def("rasterize_view_step", &rasterize_view_step);
-    m.def("rasterize_gaussians_raw_backward_adam", &rasterize_gaussians_raw_backward_adam);
-    m.def("adam_rest_step", &adam_rest_step);
+    m.def("adam_step_masked", &adam_step_masked);
     m.def("check", &check);
     m.def("header_post", &header_post);
     m.def("request_early_header", [] { lr_request_early_header(); });

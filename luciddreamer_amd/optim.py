@@ -35,7 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._fused_pending = None       # (geom buffer, params, step) of a backward that took this step's visited rows
+        self._fused_pending = None       # (geom buffer, params, their gradient tensors -- visited rows only) of an armed backward
 
     # ---- the step taken by the backward pass (lr_backward_raw_adam) ------------------------------------------
     def _fused_groups(self):
@@ -63,14 +63,19 @@ class FusedAdam(torch.optim.Optimizer):
 
     def arm_fused_backward(self) -> bool:
         """The NEXT raw-mode rasterizer backward over exactly this optimizer's six GaussianModel tensors (groups named
-        xyz / f_dc / f_rest / opacity / scaling / rotation, one tensor each) takes this optimizer's step for the Gaussians it
-        visits instead of storing their gradients (lr_backward_raw_adam); the step() that follows finishes it for the rest
-        (lr_adam_rest_step).  Parameters and moments after the pair are bit-identical to backward + step(); param.grad stays
-        None.  For a loop in which EVERY armed backward is followed by exactly one step() with no other gradient source and no
-        change of the parameter set in between (R/luciddreamer.py:296-327 on iterations that neither densify nor reset
-        opacities: luciddreamer_amd.install(..., fuse_step=True) arms from update_learning_rate by that schedule).  Anything
-        else is refused loudly: step() raises if a parameter was replaced or received a .grad while a fused step was pending.
-        Returns False (nothing armed) when the groups do not have that shape."""
+        xyz / f_dc / f_rest / opacity / scaling / rotation, one tensor each) hands its gradients to this optimizer PRIVATELY:
+        it writes only the rows of the Gaussians the view visits into tensors the optimizer keeps until step() (no zero-fill of the other rows:
+        LR_ACC_NO_ZERO_FILL) and returns no gradient to autograd -- param.grad stays None -- and the step() that follows runs
+        lr_adam_step_masked, which takes the gradient of an unvisited Gaussian as zero without reading it.  Gone per iteration:
+        the zero-fill pass over 236 B per Gaussian, the read of those zeros, the allocation of six gradient tensors.
+        Parameters and moments after the pair are bit-identical to backward + step().  For a loop in which EVERY armed backward
+        is followed by exactly one step() with no other gradient source and no change of the parameter set in between
+        (R/luciddreamer.py:296-327 on iterations that neither densify nor reset opacities:
+        luciddreamer_amd.install(..., fuse_step=True) arms from update_learning_rate by that schedule).  What the library can
+        see of a deviation is refused loudly: step() raises if a parameter was replaced or received a .grad meanwhile.
+        Returns False (nothing armed) when the groups do not have that shape.
+        (Round 6 first took the step INSIDE the per-Gaussian backward kernel: the same bits, no faster -- the step's 24 B per
+        element are moved at 1.6-3.9 TB/s there against 5 TB/s by a streaming kernel; profiles/r06n_*.)"""
         global _armed
         if self._fused_pending is not None:
             raise RuntimeError("FusedAdam.arm_fused_backward: the previous fused backward has not been finished by step()")
@@ -86,34 +91,28 @@ class FusedAdam(torch.optim.Optimizer):
         if _armed is self:
             _armed = None
 
-    def fused_backward_args(self):
-        """Called by the rasterizer's backward once it has taken this optimizer (take_armed): advances the step counts and returns
-        (exp_avg[6], exp_avg_sq[6], lrs[6], beta1, beta2, eps, step) for lr_backward_raw_adam."""
-        groups = self._fused_groups()
-        states = [self._state_of(g["params"][0]) for g in groups]
-        steps = {int(st["step"].item()) for st in states}
-        if len(steps) != 1:
-            raise RuntimeError("FusedAdam: the six tensors have different step counts; the fused backward needs one")
-        for st in states:
-            st["step"] += 1
-        step = steps.pop() + 1
-        b1, b2 = groups[0]["betas"]
-        return ([st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states], [float(g["lr"]) for g in groups],
-                float(b1), float(b2), float(groups[0]["eps"]), step)
-
     def _finish_fused(self):
         from . import _C
-        geom, params, args = self._fused_pending
+        geom, params, bufs = self._fused_pending
         self._fused_pending = None
         now = self._fused_params()
         if now is None or any(a is not b for a, b in zip(now, params)):
-            raise RuntimeError("FusedAdam.step: the parameter set changed between a fused backward and step() -- the step of the "
-                               "visited Gaussians has already been taken; do not arm iterations that densify / prune / replace tensors")
+            raise RuntimeError("FusedAdam.step: the parameter set changed between an armed backward and step(): its gradients belong "
+                               "to the old tensors; do not arm iterations that densify / prune / replace tensors")
         if any(p.grad is not None for p in params):
-            raise RuntimeError("FusedAdam.step: a parameter received a .grad while a fused step was pending (a second backward, or "
-                               "another loss term): its gradient would be lost; do not arm such iterations")
+            raise RuntimeError("FusedAdam.step: a parameter received a .grad while an armed backward's gradients were pending (a "
+                               "second backward, or another loss term): the two cannot be combined; do not arm such iterations")
+        groups = self._fused_groups()
+        states = [self._state_of(p) for p in params]
+        steps = {int(st["step"].item()) for st in states}
+        if len(steps) != 1:
+            raise RuntimeError("FusedAdam: the six tensors have different step counts; the masked step needs one")
+        for st in states:
+            st["step"] += 1
+        b1, b2 = groups[0]["betas"]
         with torch.cuda.device(params[0].device):
-            _C.adam_rest_step(geom, *params, *args)
+            _C.adam_step_masked(list(params), list(bufs), [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
+                                [float(g["lr"]) for g in groups], float(b1), float(b2), float(groups[0]["eps"]), steps.pop() + 1, geom)
         return set(id(p) for p in params)
 
     @torch.no_grad()

@@ -228,19 +228,19 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_dc, g_rest = leaf_grad(li["features_dc"]), leaf_grad(li["features_rest"])
             if g_dc is not None and (g_rest is not None or features_rest.numel() == 0):
                 accumulate_into["features"] = (g_dc, g_rest)
-        # an armed FusedAdam over exactly these six tensors (optim.FusedAdam.arm_fused_backward): the kernels take its step for
-        # the Gaussians they visit instead of storing their gradients; optimizer.step() finishes it.  param.grad stays None.
+        # an armed FusedAdam over exactly these six tensors (optim.FusedAdam.arm_fused_backward): the gradients go to buffers the
+        # optimizer keeps -- visited rows only, nothing zero-filled -- and its step() reads them through the view's own
+        # visibility (lr_adam_step_masked).  Autograd gets no parameter gradient: param.grad stays None.
         from . import optim
         opt = optim.take_armed((xyz, features_dc, features_rest, opacity, scaling, rotation)) \
             if (optim._armed is not None and not rs.debug and all(ctx.needs_input_grad[k] for k in (0, 2, 4, 5, 6))) else None
         if opt is not None:
-            args = opt.fused_backward_args()
-            g_means2D = _C.rasterize_gaussians_raw_backward_adam(
+            g = _C.rasterize_gaussians_raw_backward(
                 rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
-                binning, img, False, ctx.binning_capacity, *args)
-            opt._fused_pending = (geom, [xyz, features_dc, features_rest, opacity, scaling, rotation], args)
-            return None, g_means2D, None, None, None, None, None, None
+                binning, img, False, binning_capacity=ctx.binning_capacity, no_zero_fill=True)
+            opt._fused_pending = (geom, [xyz, features_dc, features_rest, opacity, scaling, rotation], list(g[1:]))
+            return None, g[0], None, None, None, None, None, None
         g = _C.rasterize_gaussians_raw_backward(
             rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
             rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom, ctx.num_rendered,

@@ -138,7 +138,7 @@ def test_coefficients_above_the_active_sh_degree_stay_untouched_and_equal_torch(
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# The optimizer step taken BY the backward pass (lr_backward_raw_adam + lr_adam_rest_step; optim.FusedAdam.arm_fused_backward)
+# The armed pair: backward without zero-fill + masked step (LR_ACC_NO_ZERO_FILL + lr_adam_step_masked; optim.FusedAdam.arm_fused_backward)
 # ---------------------------------------------------------------------------------------------------------------------
 def _two_clouds(P, dev, seed=7):
     from luciddreamer_amd import synthetic
@@ -160,9 +160,9 @@ def _adam_for(cloud):
 @pytest.mark.parametrize("W,H", [(320, 192), (1280, 720)])
 def test_step_taken_by_the_backward_gives_the_bits_of_backward_plus_step(hip_device, W, H):
     """Same cloud twice, same views, same upstream gradients.  A: raw-mode backward writes the gradients, FusedAdam.step()
-    applies them (lr_backward_raw + lr_adam_step).  B: the optimizer is armed, the backward's per-Gaussian kernel takes the step
-    for the Gaussians the view touches and step() takes it for the rest with gradient zero (lr_backward_raw_adam +
-    lr_adam_rest_step).  After every iteration all six parameter tensors and both moments must be the SAME BITS, and so must
+    applies them (lr_backward_raw + lr_adam_step).  B: the optimizer is armed, the backward writes only the rows of the Gaussians
+    the view touches into tensors autograd never sees (LR_ACC_NO_ZERO_FILL) and step() takes every other gradient as zero without
+    reading it (lr_adam_step_masked).  After every iteration all six parameter tensors and both moments must be the SAME BITS, and so must
     the screen-space gradients the densification statistics read -- over views that see a fraction of the band cloud (most
     rows are 'the rest'), with the SH degree raised and a learning rate changed on the way, and an un-armed iteration in between."""
     from luciddreamer_amd import cameras, synthetic
