@@ -440,13 +440,13 @@ void lr_backward_wait_event(void* event);
  *   "strict" 1           the blend in the reference's own float operations (luciddreamer_amd.config.set_strict_parity)
  *   "views_in_flight" n  hint: the caller keeps n views' kernels in flight on different streams (parallel.ViewStreams)
  *   "blend_quad" 0/1/2   blend backward: 2 waves per tile / 4 waves per tile / 1 wave per tile
- *   "fwd_pair" 0/1/2     blend forward: quadrant kernel / with candidate pairs / 1 wave per tile
+ *   "fwd_pair" 0/2       blend forward: quadrant kernel / 1 wave per tile
  *   "tile_map" 0/1       tile -> workgroup map: XCD bands / plain
  *   "bwd_seg" 0          the blend backward walks whole lists instead of 256-position segments
  *   "bwd_red" 4          every wave of the blend backward takes the loop copy with the `pos < last` test
  *   "preprocess" 0/1     plain / pooled preprocess kernel;  "hit_mask" 0: no tile masks;  "tsort" 0/1/2, "walk_own" n: binning
  *   "gauss_bwd" 0        no interleaved step accumulator
- * Values that select a RETIRED kernel ("part_scan", "bwd_red" 0 / 3) and every LR_* environment override exist only in the
+ * Values that select a RETIRED kernel ("part_scan", "bwd_red" 0 / 2 / 3, "fwd_pair" 1) and every LR_* environment override exist only in the
  * diagnostics build (-DLR_DIAGNOSTICS, `python -m luciddreamer_amd.build --diagnostics`; lr_version() then says "+diagnostics");
  * the product library rejects them with LR_ERR_INVALID_ARG and reads no environment variable. */
 int lr_tune_set(const char* name, int value);

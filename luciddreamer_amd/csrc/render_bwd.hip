@@ -782,19 +782,18 @@ int blend_shape(int num_tiles)
     static const int forced = env_knob("LR_BLEND_QUAD_BWD");
     if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD);
     if (forced >= 0) return forced;
-    // The backward blend pays its cross-lane reduction per wave and candidate.  Small images (every workgroup resident at once:
-    // the kernel time is the longest per-wave chain): the quadrant shape shortens the chain (dense 1 M cloud, single view:
-    // 256^2 0.22 -> 0.13 ms, 512^2 0.51 -> 0.42, 800^2 0.58 -> 0.53, 1024^2 equal, 1280x720 0.42 -> 0.44).
-    if (num_tiles <= 3072) return BLEND_QUAD;
-    // Large images, measured on MI355X (profiles/r04a_ab_bwd_shape.json, r04b_ab_bwd_tile8.json; us single stream / views/s
-    // with three views in flight, 2-wave shape -> one wave per tile): C3 91.7 -> 96.0 us but 5020-5160 -> 5200-5245 views/s;
-    // dense 1 M cloud 466 -> 458 us, 1110-1124 -> 1163-1166 views/s; 3 M / 1440p 896 -> 896 us, 454-461 -> 460-467 views/s.
-    // The TILE shape issues 1.5 % fewer VALU instructions and 3.2 % fewer VALU cycles (PMC: 48.66 M -> 47.9 M instructions,
-    // SQ_ACTIVE_INST_VALU 54.3 M -> 52.6 M per C3 launch: the reduction's swaps and DPP adds are paid per tile instance
-    // instead of per half tile reached, the dy bookkeeping it adds is plain multiplies), but its 8160 waves -- all resident
-    // at once, all in the same phase -- expose their staging latencies together when the kernel has the GPU to itself.  So:
-    // one wave per tile when other views' kernels fill those gaps, the 2-wave shape for a lone view.
-    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_HALF;
+    // Round 6 rule, from tools/shape_sweep.py on the final kernels (profiles/r06q_shape_sweep.json: every forced pair of
+    // forward / backward shapes on six workloads, three views in flight and one; tests/test_gpu_heuristics.py keeps it honest):
+    //   * large images (> 3072 tiles): one wave per tile.  Since its reduction goes through LDS and it no longer spills (round 6)
+    //     it beats the 2-wave shape also for a lone view: C2 +5 %, C3 +1.5 %, dense 1080p +6.8 %, 3 M / 1440p +3.3 % views/s
+    //     (three views in flight: +3 ... +8 %).  [Rounds 4-5 picked the 2-wave shape for a lone view.]
+    //   * small images: every workgroup is resident from the start and the kernel lasts as long as its longest per-wave chain --
+    //     the 4-wave shape shortens the chain of a LONE view (pixel-sized splats at 512^2: 4130 against 3890 / 3340 views/s for
+    //     2 / 1 waves; dense 1 M cloud: the three within 2 %), but with other views in flight the chains overlap anyway and the
+    //     shape that issues the fewest instructions wins: dense 1 M cloud at 512^2 1967 (1 wave) / 1917 (2) / 1787 (4) views/s,
+    //     pixel-sized splats 5960 / 6020 / 5800.
+    if (num_tiles > 3072) return BLEND_TILE;
+    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_QUAD;
 }
 
 // shapes of the process's last blend launches (lr_last_launch_shapes: tests assert which kernels a configuration ran; process-wide,

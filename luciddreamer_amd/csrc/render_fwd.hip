@@ -424,21 +424,25 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     if (num_tiles <= 0) return;
     const int tile_map = blend_tile_map(num_tiles);
     const int grid = ((num_tiles + 7) / 8) * 8;
-    // Shape (same images, depth, checkpoints and gradients to the bit from all three):
-    //   quadrant kernel (4 waves per tile) -- small images, and a lone large view: 52 us at C3 against the tile kernel's 64;
-    //   ... with candidate pairs -- images of <= 3072 tiles (lists of PAIR_MIN_LIST and more);
+    // Shape (same images, depth, checkpoints and gradients to the bit from all of them):
+    //   quadrant kernel (4 waves per tile) -- small images, a lone large view, and large images of long lists;
     //   tile kernel (1 wave per tile) -- large images while other views' kernels are in flight: 10 % fewer VALU instructions and
-    //   59 % fewer LDS reads per C3 view (28.7 M -> 25.7 M, 3.10 M -> 1.26 M; profiles/r05x_pmc_fwdtile_*.json) but only 3.4 of its
-    //   7 waves per SIMD resident on average when it has the GPU to itself.  Three views in flight, quadrant -> tile kernel
-    //   (profiles/r05u_ab_fwd_tile.json, r05v_, r05w_: three boxes): C3 +1.8 ... +3.2 % views/s, C2 +2.1 ... +3.6 %,
-    //   3 M / 1440p (700 instances per tile) -0 ... +1 %, dense 1 M cloud at 1080p (460 per tile) -2 ... -3 %.  So: the rule of
-    //   the backward's shapes (render_bwd.hip blend_shape), and not on scenes whose earlier views told the host that the lists
-    //   are longer than a staging round of the quadrant kernel on average (inst_hint: api.hip view_hint_instances; -1 = unknown).
-    // lr_tune_set("fwd_pair", 0 / 1 / 2) forces quadrant / quadrant with pairs / tile (A/B runs).
+    //   59 % fewer LDS reads per C3 view (28.7 M -> 25.7 M, 3.10 M -> 1.26 M; profiles/r05x_pmc_fwdtile_*.json).  Three views in
+    //   flight, quadrant -> tile kernel (profiles/r06q_shape_sweep.json): C2 +2.5 %, C3 +1 %, 3 M / 1440p (700 instances per
+    //   tile) +0.5 %, dense 1 M cloud at 1080p (460 per tile) -1.8 %; a lone view: -2 ... -8 %.  So: large images with other views
+    //   in flight, and not on scenes whose earlier views told the host that the lists are longer than a staging round of the
+    //   quadrant kernel on average (inst_hint: api.hip view_hint_instances; -1 = unknown).
+    //   [Round 5's candidate-PAIR variant of the quadrant kernel (small images, lists of 1024 and more) no longer pays on any
+    //    workload of the sweep (-0.5 ... -1.6 %): diagnostics build only.]
+    // lr_tune_set("fwd_pair", 0 / 2) forces quadrant / tile (tests, A/B runs); 1 = the pair variant (diagnostics build).
     const int knob = tune_get(TUNE_FWD_PAIR);
     const bool long_lists = inst_hint > (long long)BATCH * num_tiles;
     const bool tile_shape = knob >= 0 ? knob == 2 : (num_tiles > 3072 && views_in_flight() >= 2 && !long_lists);
-    const bool pair = knob >= 0 ? knob == 1 : num_tiles <= 3072;
+#ifdef LR_DIAGNOSTICS
+    const bool pair = knob == 1;
+#else
+    constexpr bool pair = false;
+#endif
     const bool strict = tune_get(TUNE_STRICT) > 0;
     note_fwd_shape(tile_shape ? 2 : pair ? 1 : 0);
 #define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
@@ -449,8 +453,10 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
         return;
     }
 #define LR_FWD(S, PR) hipLaunchKernelGGL((k_render_fwd<S, PR>), dim3(grid), dim3(THREADS), 0, s, LR_FWD_ARGS)
-    if (strict) { if (pair) LR_FWD(true, true); else LR_FWD(true, false); }
-    else { if (pair) LR_FWD(false, true); else LR_FWD(false, false); }
+#ifdef LR_DIAGNOSTICS
+    if (pair) { if (strict) LR_FWD(true, true); else LR_FWD(false, true); return; }
+#endif
+    if (strict) LR_FWD(true, false); else LR_FWD(false, false);
 #undef LR_FWD_ARGS
 #undef LR_FWD
 }

@@ -1,0 +1,42 @@
+"""The kernel shape the library picks by rule (render_bwd.hip blend_shape, render_fwd.hip launch_render_fwd) against every shape
+it could have been forced to, on the BASELINE.json workload shapes and on LucidDreamer's own scene statistics (ld512), with three
+views in flight and with one: the rule's step must be within 3 % of the best forced one.  A reduced form of
+tools/shape_sweep.py (profiles/r06q_shape_sweep.json is the full sweep the rule was written from): smaller view counts, the two
+kernels varied one at a time."""
+import argparse
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (workload, views per step): the 3 M / 1440p shape is left to the tool (tens of seconds per sweep)
+CASES = [("c3", 9), ("c2", 9), ("c3box", 6), ("c5shape", 9), ("ld512", 12)]
+
+
+@pytest.mark.parametrize("name,views", CASES)
+@pytest.mark.parametrize("in_flight", [3, 1])
+def test_the_rule_picks_a_shape_within_3_percent_of_the_best(hip_device, name, views, in_flight):
+    import bench
+    from luciddreamer_amd import _lib, config
+    args = argparse.Namespace(sh_degree=3, no_fused_accumulate=False, gaussians=None, exchange="allreduce")
+    wl = bench.Workload(name, args, 0, 1, hip_device, views=views)
+    combos = [(-1, -1), (0, -1), (1, -1), (2, -1), (-1, 0), (-1, 2)]          # the rule; each backward shape; each forward shape
+    best = {}
+    try:
+        for _ in range(3):
+            for b, f in combos:
+                _lib.tune_set("blend_quad", b)
+                _lib.tune_set("fwd_pair", f)
+                v, _, _, _ = bench.run_leg(wl, "views", False, in_flight, 4, 1, 1, hip_device)
+                best[(b, f)] = max(best.get((b, f), 0.0), v)
+    finally:
+        _lib.tune_set("blend_quad", -1)
+        _lib.tune_set("fwd_pair", -1)
+        config.reset()
+        del wl
+        torch.cuda.empty_cache()
+    rule = best.pop((-1, -1))
+    top = max(best.values())
+    print(f"{name} {in_flight} in flight: rule {rule:.1f} views/s, best forced {top:.1f} ({max(best, key=best.get)}), ratio {rule / top:.3f}")
+    assert rule >= 0.97 * top, (name, in_flight, rule, best)
