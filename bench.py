@@ -398,6 +398,7 @@ def profiled_stages(wl, api, exact, steps, world, dev, args, views_in_flight):
         stages = _lib.profile_read()
         _lib.profile_enable(False)
         wl.finish()
+        wl.last_profiled_shapes = _lib.last_launch_shapes()      # (forward, backward) kernel shapes of this pass
     finally:
         _lib.tune_set("views_in_flight", -1)
     return stages, dt_prof
@@ -411,12 +412,13 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     from luciddreamer_amd import _lib
     in_flight = args.streams if api in ("views", "views-loss", "autograd") else 1
     stages, dt_prof = profiled_stages(wl, api, exact, steps, world, dev, args, in_flight)
-    lone = None
+    shapes = getattr(wl, "last_profiled_shapes", (None, None))
+    lone, lone_shapes = None, (None, None)
     if in_flight >= 2:
         lone = profiled_stages(wl, api, exact, steps, world, dev, args, 1)[0]
-    # name of the blend-backward kernel each of the two passes launched (the rule of render_bwd.hip blend_shape; the forward
-    # follows it: render_fwd.hip launch_render_fwd)
-    bwd_tile = wl.T > 3072 and in_flight >= 2
+        lone_shapes = getattr(wl, "last_profiled_shapes", (None, None))
+    # name of the blend-backward kernel the pass launched (lr_last_launch_shapes: the rule of render_bwd.hip blend_shape)
+    bwd_tile = shapes[1] == "tile"
     bwd_name = "k_render_bwd_tile" if bwd_tile else "k_render_bwd<"
     P, V_mean, R_mean, N, T, K, M, V = wl.P, wl.V_mean, wl.R_mean, wl.N, wl.T, wl.K, wl.M, wl.V
     single_kernel = ("preprocess", "render_fwd", "render_bwd", "gauss_bwd")
@@ -514,7 +516,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     if lone is not None:
         ms, calls = lone[dom]
         avg = ms / max(calls, 1) * 1e-3
-        lone_shape = {"kernel": "k_render_bwd<...> (2 waves per tile)" if dom == "render_bwd" and wl.T > 3072 else "k_" + dom,
+        lone_shape = {"kernel": "k_" + dom, "kernel_shapes": {"forward": lone_shapes[0], "backward": lone_shapes[1]},
                       "avg_launch_ms": round(avg * 1e3, 4), "achieved": round(dom_bytes / avg / 1e9, 2),
                       "frac": round(dom_bytes / avg / 1e9 / HBM_PEAK_GBS, 5),
                       "what": "the same stage as a lone view gets it (views_in_flight = 1)"}
@@ -529,6 +531,7 @@ def roofline_leg(wl, api, exact, steps, world, dev, value, args):
     return {
         "bound": "hbm", "kernel": dom_kernel or (bwd_name.rstrip("<") if dom == "render_bwd" else "k_" + dom),
         "kernel_is_what_the_headline_launched": True, "views_in_flight_hint": in_flight,
+        "kernel_shapes": {"forward": shapes[0], "backward": shapes[1]},
         "lone_view_shape": lone_shape, "per_stage": per_stage,
         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": source,

@@ -435,6 +435,7 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
             const int K = (vp.D + 1) * (vp.D + 1);
             const size_t shrow = (size_t)vp.M * 3;
             const bool acc = (accum_mask >> ACC_SH) & 1u;
+            const bool no_fill = !acc && (accum_mask >> 31) != 0u;          // LR_ACC_NO_ZERO_FILL (lucid_raster.h)
             const int n_here = (int)min((uint32_t)GB_THREADS, n - t0);
             if (live) {
                 const uint8_t cb = clamped[idx];
@@ -497,6 +498,13 @@ k_gauss_bwd(ViewParams vp, const float* __restrict__ means3D, const float* __res
                         if (onv[q]) {
                             float* dp = ((RAW && k != 0) ? vp.dL_dsh_rest : dL_dsh) + rowv[q];   // onv[q] holds here
                             dp[0] = dv[q][0] + bk * r0; dp[1] = dv[q][1] + bk * r1; dp[2] = dv[q][2] + bk * r2;
+                        } else if (no_fill && g < n_here && k >= K && k < vp.M) {
+                            // LR_ACC_NO_ZERO_FILL: nobody zero-filled the tensor, and a VISITED Gaussian's rows are read by the
+                            // masked optimizer step -- its coefficients above the active degree are written as the zeros they are
+                            const size_t gi = (size_t)s_idx[g];
+                            float* dp = !RAW ? dL_dsh + gi * shrow + 3 * k
+                                             : (k == 0 ? dL_dsh + gi * 3 : vp.dL_dsh_rest + gi * (shrow - 3) + 3 * (size_t)(k - 1));
+                            dp[0] = 0.f; dp[1] = 0.f; dp[2] = 0.f;
                         }
                         const float sd = onv[q] ? sv[q][0] * r0 + sv[q][1] * r1 + sv[q][2] * r2 : 0.f;
                         const float px = row_sum(s_b[1][gls * BST + ks] * sd);

@@ -692,7 +692,10 @@ class ViewStreams:
 
     def _pop_policy(self):
         """Leaves the step's policy / tuning state; a step still open here did not reach end_step() (it closes the step itself
-        first): an exception in the caller's loop -- what it accumulated is dropped."""
+        first): an exception in the caller's loop.  ABORTED STEP = UNDEFINED GRADIENTS: the five small rows of the views already
+        run (means2D, opacity, means3D, scales, rotations) were still in the library's interleaved accumulator and are dropped,
+        while their SH / colour gradients went straight into .grad and stay there.  A caller that catches the exception must zero
+        the gradient tensors before the next step (FlatGrads.zero_()) and must not step the optimizer on what is left."""
         from . import _lib
         self._close_step(torch.cuda.current_stream(self.device), abort=True)
         if getattr(self, "_policy", None) is not None:

@@ -195,6 +195,10 @@ def test_step_taken_by_the_backward_gives_the_bits_of_backward_plus_step(hip_dev
         opt_a.zero_grad(set_to_none=True)
         if armed:
             assert opt_b.arm_fused_backward()
+            # the armed backward's gradient tensors are NOT zero-filled: poison the allocator's cache, so that whatever the
+            # backward leaves unwritten and the masked step then reads is NaN, not the zeros of fresh memory
+            junk = [torch.full_like(getattr(b, n), float("nan")) for n in names]
+            del junk
         pb = render_raw(cam, b, bg_color=bg)
         (pb["render"] * g).sum().backward()
         if armed:

@@ -97,10 +97,15 @@ void run(const char* name, unsigned long long* dticks, float* dsink)
         hipMemcpy(t.data(), dticks, t.size() * 8, hipMemcpyDeviceToHost);
         std::sort(t.begin(), t.end());
         const double med = (double)t[t.size() / 2], n = (double)ITER * 8;
-        // s_memtime on gfx950 counts at a fixed 100 MHz reference, or shader cycles: print both readings of it
-        // resident together? then the launch lasts about as long as one wave (ticks / launch time = the shader clock, ~2 GHz)
-        printf(" | W=%d %5.2f cyc/instr/SIMD (%5.2f per wave; wave %4.0f us of a %4.0f us launch at 2.1 GHz)", W, med / (n * W), med / n,
-               med / 2.1e3, ms * 1e3);
+        // Two readings.  (a) one wave's own clock (s_memtime ticks between its first and last instruction) / its instructions:
+        // what ONE wave sees -- only a per-SIMD figure if the W waves of a SIMD ran side by side, which the launch does not
+        // guarantee (the 256 * W blocks are not co-resident from start to end; round 5 divided (a) by W and printed
+        // 1.21 "cycles per instruction and SIMD" for v_fma_f32, below the 2-cycle floor).  (b) the LAUNCH: every SIMD executes
+        // W x n instructions of this kind whatever the residency, so launch time x clock / (W n) is the SIMD's average issue
+        // interval -- the throughput figure, valid for every W (it includes the launch's ramp: read it at W >= 2).
+        const double clock_ghz = 2.4;
+        printf(" | W=%d launch %6.1f us -> %5.2f cyc/instr/SIMD; one wave %5.2f cyc/instr by its own clock", W, ms * 1e3,
+               ms * 1e-3 * clock_ghz * 1e9 / (n * W), med / n);
     }
     printf("\n");
 }
