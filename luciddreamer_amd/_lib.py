@@ -170,7 +170,7 @@ def diagnostics_build():
     return b"+diagnostics" in lib().lr_version()
 
 
-FWD_SHAPES = {-1: None, 0: "quadrant", 1: "quadrant-pairs", 2: "tile", 3: "split"}
+FWD_SHAPES = {-1: None, 0: "quadrant", 1: "quadrant-pairs", 2: "tile"}
 BWD_SHAPES = {-1: None, 0: "half", 1: "quad", 2: "tile"}
 
 

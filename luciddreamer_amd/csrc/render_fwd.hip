@@ -246,218 +246,12 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
 }
 
 
-// The SPLIT shape of the forward (round 6; small images): EIGHT waves per tile -- per 8x8 quadrant one PRODUCER wave and one
-// CONSUMER wave.  On a small image every workgroup is resident from the start and the kernel lasts as long as the longest
-// per-wave chain of its longest list (512^2, 1 M Gaussians: 1 700 instances per tile on average, VALU busy 49 %, 2.2 of 4 waves
-// per SIMD resident on average; profiles/r05a_pmc_c5shape.json).  Per candidate that chain is: three broadcast LDS reads -> row
-// terms -> exponent -> v_exp -> opacity x, clamp -> the recursion T' = T (1 - alpha), the stop test, five accumulations.  Only the
-// recursion is sequential along the list.  So the producer culls the staged Gaussians against the quadrant, evaluates alpha for
-// the quadrant's 64 pixels (the same instructions on the same operands: the same bits), masks it with the reference's skip tests
-// (power > 0, alpha < 1/255 -> 0) and leaves a row {alpha[64], colour, depth, list position} in an LDS ring; the consumer walks
-// the ring in list order and carries T, the colour and depth sums, the stop position and the checkpoints -- 12 VALU instructions
-// per candidate instead of 22, one LDS row read and one broadcast read instead of three broadcast reads.  alpha = 0 IS "skipped"
-// for the consumer (a blended alpha is >= 1/255).  Twice the waves per SIMD hide each other's latencies on top.
-// Flow control: two counters per quadrant in LDS (rows published / rows consumed, updated every SP_PUB rows), polled with
-// s_sleep; a workgroup barrier pair per staging round as in k_render_fwd (the consumer reaches it only when the producer has
-// published the round's end and every row is consumed; the producer only after publishing: no wave waits at a barrier for rows).
-// A consumer whose 64 pixels are all finished raises s_qdone; its producer stops at the next poll.
-constexpr int SP_THREADS = 512;
-constexpr int SP_ROWS = 16;         // ring rows per quadrant (4 x 16 x 256 B = 16 KB + 14 KB of staged fields: 4 workgroups per CU)
-constexpr int SP_PUB = 4;           // rows per publication / release
-constexpr uint32_t SP_SPIN_LIMIT = 1u << 24;       // a poll loop gives up after this many turns (a bug must not hang the GPU)
-template <bool STRICT>
-__global__ void __launch_bounds__(SP_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_render_fwd_split(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
-                   const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
-                   const GaussRec* __restrict__ rec,
-                   const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
-                   float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
-                   GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,
-                   uint32_t* __restrict__ tile_seg0, float4* __restrict__ c_final)
-{
-    __shared__ float4 s_q0[BATCH];      // as k_render_fwd
-    __shared__ float4 s_q1[BATCH];
-    __shared__ float4 s_q2[BATCH];
-    __shared__ float2 s_q3[BATCH];
-    __shared__ float s_alpha[4][SP_ROWS][64];
-    __shared__ float4 s_row[4][SP_ROWS];            // r, g, b, depth of the row's Gaussian
-    __shared__ uint32_t s_rpos[4][SP_ROWS];         // its list position
-    __shared__ uint32_t s_prod[4], s_cons[4], s_rdone[4], s_qdone[4];
-    __shared__ int s_wdone[4];
-    __shared__ uint32_t s_seg0;
-
-    const int tile = blend_tile(tile_map, num_tiles);
-    if (tile < 0) return;
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, w = tid >> 6, l = tid & 63;
-    const bool producer = w >= 4;
-    const int q = w & 3;                                                            // the wave's quadrant
-    const int x0 = tx * TILE_X + (q & 1) * 8, y0 = ty * TILE_Y + (q >> 1) * 8;
-    const int px = x0 + (l & 7), py = y0 + (l >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const float bx0 = (float)x0, bx1 = (float)(x0 + 7), by0 = (float)y0, by1 = (float)(y0 + 7);
-
-    const uint2 range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-
-    PixState A = { 1.0f, 0.f, 0.f, 0.f, 0.f, 0.000001f, 0u };
-    uint64_t done = __builtin_amdgcn_ballot_w64(!inside);
-    bool wave_done = done == ~0ull;                                                  // consumer: its 64 pixels are finished
-    volatile uint32_t* v_prod = s_prod; volatile uint32_t* v_cons = s_cons;
-    volatile uint32_t* v_rdone = s_rdone; volatile uint32_t* v_qdone = s_qdone;
-    if (tid < 4) { s_prod[tid] = 0u; s_cons[tid] = 0u; s_rdone[tid] = 0u; s_qdone[tid] = 0u; }
-
-    const int n_seg = total > 0 ? (total - 1) / BWD_SEG : 0;
-    uint32_t seg0 = 0;
-    int n_ck = 0;
-    if (n_seg > 0) {
-        if (tid == 0) { s_seg0 = atomicAdd(&hdr->n_seg, (uint32_t)n_seg); tile_seg0[tile] = s_seg0; }
-        lds_barrier();
-        seg0 = s_seg0;
-        for (int g = 1 + tid; g <= n_seg; g += SP_THREADS) seg_list[seg0 + g - 1] = make_uint2((uint32_t)tile, (uint32_t)g);
-    }
-
-    uint32_t n_rows = 0;            // producer: rows written; consumer: rows consumed (both count over the whole list)
-    uint32_t round_no = 0;
-    for (int base = 0; base < total; base += BATCH) {
-        if (!producer && l == 0) s_wdone[q] = wave_done ? 1 : 0;
-        lds_barrier();              // (also: the counters' initial values, the previous round's staged fields are free)
-        if (s_wdone[0] + s_wdone[1] + s_wdone[2] + s_wdone[3] == 4) break;
-        const int cnt = min(BATCH, total - base);
-        round_no++;
-        if (!producer) {
-            if (base > 0 && !wave_done) {
-                ckpt[(size_t)(seg0 + n_ck) * TILE_PIX + tid] = make_float4(A.T, A.Cr, A.Cg, A.Cb);     // tid = q * 64 + l here
-                n_ck++;
-            }
-            if (tid < cnt) {
-                const uint32_t id = inst_gid[point_list[range.x + base + tid]];
-                const float4* g = reinterpret_cast<const float4*>(rec + id);
-                const float4 a = g[0], b = g[1], c = g[2];
-                s_q0[tid] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);
-                s_q1[tid] = STRICT ? make_float4(b.x, b.y, c.y, c.z) : make_float4((-0.5f * LOG2E) * b.x, b.y, c.y, LOG2E * c.z);
-                s_q2[tid] = make_float4(b.z, b.w, c.x, 0.f);
-                s_q3[tid] = make_float2(-a.w / b.x, -a.w / a.z);
-            }
-        }
-        lds_barrier();
-
-        if (producer) {
-            bool stop = s_wdone[q] != 0 || v_qdone[q] != 0u;       // (s_wdone: as of this round's top, e.g. a quadrant outside the image)
-            for (int sb = 0; sb < cnt && !stop; sb += 64) {
-                bool hit = false;
-                const int jl = sb + l;
-                if (jl < cnt) {
-                    const float4 a = s_q0[jl];
-                    const float4 b = s_q1[jl];
-                    const float2 r = s_q3[jl];
-                    const float ca = STRICT ? a.z : -2.0f * a.z, cb = STRICT ? a.w : -a.w, cc = STRICT ? b.x : -2.0f * b.x;
-                    hit = box_hit(a.x, a.y, ca, cb, cc, r.x, r.y, b.w, bx0, bx1, by0, by1);
-                    quad_hits[4 * ((size_t)range.x + (size_t)(base + jl)) + q] = hit ? 1 : 0;
-                }
-                uint64_t mask = __ballot(hit);
-                while (mask) {
-                    if ((n_rows & (SP_PUB - 1)) == 0u) {
-                        // room for SP_PUB more rows?  (rows n_rows .. n_rows + SP_PUB - 1 re-use the slots of rows SP_ROWS earlier)
-                        uint32_t spins = 0;
-                        while (n_rows + SP_PUB - v_cons[q] > (uint32_t)SP_ROWS) {
-                            if (v_qdone[q] != 0u || ++spins > SP_SPIN_LIMIT) { stop = true; break; }
-                            __builtin_amdgcn_s_sleep(1);
-                        }
-                        if (stop) break;
-                    }
-                    const int k = __ffsll((long long)mask) - 1;
-                    mask &= mask - 1;
-                    const int j = sb + k;
-                    const float4 a = s_q0[j];
-                    const float4 b = s_q1[j];
-                    float r0, r1, power;
-                    gauss_row<STRICT>(a.w, b.x, a.y - pyf, r0, r1);
-                    const float alpha = fminf(0.99f, b.y * gauss_weight<STRICT>(a.z, a.w, b.x, r0, r1, a.x - pxf, power));
-                    // the reference's skip tests (forward.cu:331-339) decided here: a skipped pixel carries alpha = 0
-                    const bool pass = power <= 0.0f && alpha >= 1.0f / 255.0f;
-                    const uint32_t row = n_rows & (SP_ROWS - 1);
-                    s_alpha[q][row][l] = pass ? alpha : 0.f;
-                    if (l == 0) {
-                        const float4 c = s_q2[j];
-                        s_row[q][row] = make_float4(c.x, c.y, c.z, b.z);
-                        s_rpos[q][row] = (uint32_t)(base + j);
-                    }
-                    n_rows++;
-                    if ((n_rows & (SP_PUB - 1)) == 0u) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (l == 0) v_prod[q] = n_rows;
-                    }
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (l == 0) { v_prod[q] = n_rows; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (l == 0) { v_rdone[q] = round_no; }                                   // after the final row count: see the consumer
-        } else if (!wave_done) {
-            uint32_t spins = 0;
-            for (;;) {
-                const uint32_t rd = v_rdone[q];                                      // FIRST: a published round end makes the count final
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t p = v_prod[q];
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                if (n_rows == p) {
-                    if (rd == round_no || ++spins > SP_SPIN_LIMIT) break;
-                    __builtin_amdgcn_s_sleep(1);
-                    continue;
-                }
-                spins = 0;
-                while (n_rows != p) {
-                    const uint32_t row = n_rows & (SP_ROWS - 1);
-                    const float alpha = s_alpha[q][row][l];
-                    const float4 c = s_row[q][row];
-                    const uint32_t pos0 = s_rpos[q][row];
-                    // fwd_pixel's recursion on the producer's alpha (alpha = 0: skipped)
-                    const float test_T = A.T * (1.0f - alpha);
-                    const uint64_t pass = ~done & __builtin_amdgcn_ballot_w64(alpha != 0.0f);
-                    const uint64_t low_T = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
-                    const uint64_t stop = pass & low_T;
-                    const bool use = __builtin_amdgcn_inverse_ballot_w64(pass & ~low_T);
-                    done |= stop;
-                    const float wgt = use ? alpha * A.T : 0.f;
-                    A.Cr += c.x * wgt; A.Cg += c.y * wgt; A.Cb += c.z * wgt; A.D += c.w * wgt; A.acc += wgt;
-                    A.T = use ? test_T : A.T;
-                    if (stop != 0ull) {
-                        asm volatile("");
-                        A.last = __builtin_amdgcn_inverse_ballot_w64(stop) ? pos0 : A.last;
-                    }
-                    n_rows++;
-                    if ((n_rows & (SP_PUB - 1)) == 0u) {
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // the rows' reads are done before the slots are released
-                        if (l == 0) v_cons[q] = n_rows;
-                    }
-                    if (done == ~0ull) break;
-                }
-                if (done == ~0ull) {
-                    wave_done = true;
-                    if (l == 0) v_qdone[q] = 1u;                                     // the producer stops at its next poll
-                    break;
-                }
-            }
-            if (l == 0) v_cons[q] = n_rows;
-        }
-    }
-
-    if (!producer && inside) {
-        const size_t N = (size_t)W * H;
-        const size_t pix = (size_t)py * W + px;
-        final_T[pix] = A.T;
-        n_contrib[pix] = __builtin_amdgcn_inverse_ballot_w64(done) ? A.last : (uint32_t)total;
-        const float fr = A.Cr + A.T * bg[0], fg = A.Cg + A.T * bg[1], fb = A.Cb + A.T * bg[2];
-        out_color[pix] = fr;
-        out_color[N + pix] = fg;
-        out_color[2 * N + pix] = fb;
-        if (n_seg > 0) c_final[pix] = make_float4(fr, fg, fb, 0.f);
-        out_depth[pix] = (A.acc > 0.5f) ? A.D / A.acc : 0.0f;
-    }
-}
-
+// (Round 6 built the producer / consumer split DESIGN.md 8.2 had proposed for small images -- eight waves per tile, per quadrant
+//  one wave evaluating alpha into an LDS ring and one carrying the recursion, counters polled with s_sleep -- and removed it again:
+//  bit-identical to the quadrant kernel on every test, and 2.2-2.4 x SLOWER (dense 512^2 168 -> 402 us, pixel-sized splats 53 -> 119
+//  us): the hand-over costs more instructions than it moves -- VALU 48.6 M -> 131 M, SALU 24.9 M -> 116 M wave-instructions per view,
+//  waves parked 140 M -> 554 M cycles (profiles/r06s_ab_fwd_split_dead_end.json, r06t_pmc_c5shape_fwd_*.json; code at commit
+//  "Forward split for small images").)
 
 // The TILE shape of the forward: ONE wave64 per 16x16 tile, a lane owns FOUR pixels -- the same position (l & 7, l >> 3) in
 // each of the tile's four 8x8 quadrants (the layout of render_bwd.hip's TILE shape).  A round stages 64 list entries, one per
@@ -651,21 +445,15 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     const int knob = tune_get(TUNE_FWD_PAIR);
     const bool long_lists = inst_hint > (long long)BATCH * num_tiles;
     const bool tile_shape = knob >= 0 ? knob == 2 : (num_tiles > 3072 && views_in_flight() >= 2 && !long_lists);
-    const bool split_shape = knob == 3;
 #ifdef LR_DIAGNOSTICS
     const bool pair = knob == 1;
 #else
     constexpr bool pair = false;
 #endif
     const bool strict = tune_get(TUNE_STRICT) > 0;
-    note_fwd_shape(split_shape ? 3 : tile_shape ? 2 : pair ? 1 : 0);
+    note_fwd_shape(tile_shape ? 2 : pair ? 1 : 0);
 #define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
                     quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
-    if (split_shape) {
-        if (strict) hipLaunchKernelGGL((k_render_fwd_split<true>), dim3(grid), dim3(SP_THREADS), 0, s, LR_FWD_ARGS);
-        else hipLaunchKernelGGL((k_render_fwd_split<false>), dim3(grid), dim3(SP_THREADS), 0, s, LR_FWD_ARGS);
-        return;
-    }
     if (tile_shape) {
         if (strict) hipLaunchKernelGGL((k_render_fwd_tile<true>), dim3(grid), dim3(64), 0, s, LR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd_tile<false>), dim3(grid), dim3(64), 0, s, LR_FWD_ARGS);

@@ -69,31 +69,6 @@ def test_random_scene_through_the_tile_kernels_matches_oracle(hip_device, seed):
         hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
 
 
-@pytest.mark.parametrize("seed", range(36, 48))
-def test_random_scene_through_the_split_forward_matches_oracle(hip_device, seed):
-    """... and through the producer / consumer forward small images get (render_fwd.hip k_render_fwd_split: per quadrant one wave
-    evaluates alpha into an LDS ring, another carries the recursion): the oracle's values, the default kernels' bits -- image,
-    depth and every gradient (the backward reads the forward's stop positions, quadrant tests and checkpoints)."""
-    from luciddreamer_amd import _lib
-    cloud, cam, degree, bg, mod, (W, H) = _scene(seed)
-    g = synthetic.upstream_grad(H, W, seed=seed)
-    ref = hp.run_oracle(cloud, cam, degree, bg, grad_color=g, scale_modifier=mod)
-    try:
-        _lib.tune_set("fwd_pair", 0)
-        plain = hp.run_hip(cloud, cam, degree, bg, hip_device, grad_color=g, scale_modifier=mod)
-        _lib.tune_set("fwd_pair", 3)
-        hip = hp.run_hip(cloud, cam, degree, bg, hip_device, grad_color=g, scale_modifier=mod)
-        assert _lib.last_launch_shapes()[0] == "split"
-    finally:
-        _lib.tune_set("fwd_pair", -1)
-    assert np.array_equal(plain["color"], hip["color"]) and np.array_equal(plain["depth"], hip["depth"])
-    for k in plain["grads"]:
-        assert np.array_equal(plain["grads"][k], hip["grads"][k]), k
-    hp.compare_forward(hip, ref, max_fragile=16)
-    if not ref["res"].stage()["fragile"].any():
-        hp.compare_grads(hip["grads"], ref["grads"], names=("means2D", "opacity", "means3D", "sh", "scales", "rotations"))
-
-
 @pytest.mark.parametrize("seed", range(6))
 def test_random_scene_raw_path_matches_activated(hip_device, seed):
     from luciddreamer_amd.gaussian_renderer import GaussianCloud, render, render_raw

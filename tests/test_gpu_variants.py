@@ -356,7 +356,7 @@ def test_forward_candidate_pairs_give_the_same_bits(hip_device, P, W, H, scale_m
     g = synthetic.upstream_grad(H, W)
     bg = torch.tensor([0.3, 0.1, 0.2])
     outs = []
-    variants = (0, 1, 2, 3) if _lib.diagnostics_build() else (0, 2, 3)       # 3: the producer / consumer split (8 waves per tile)
+    variants = (0, 1, 2) if _lib.diagnostics_build() else (0, 2)
     try:
         for v in variants:
             _lib.tune_set("fwd_pair", v)
@@ -440,7 +440,7 @@ def test_tile_forward_with_segments_and_ragged_image(hip_device, strict, n, opac
         for shape in (0, 1, 2):
             _lib.tune_set("blend_quad", shape)
             outs = []
-            for v in (0, 2, 3):                     # quadrant kernel, one wave per tile, producer / consumer split
+            for v in (0, 2):                        # quadrant kernel, one wave per tile
                 _lib.tune_set("fwd_pair", v)
                 outs.append(hp.run_hip(cloud, cam, 3, bg, hip_device, g))
             a, b = outs[0], outs[1]
