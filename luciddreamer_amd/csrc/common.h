@@ -171,7 +171,7 @@ inline ImgLayout img_layout(int W, int H) {
 // workgroup per tile for the first segment and one per listed pair: long lists (hundreds to thousands of instances per
 // tile on small images and dense clouds) no longer make the kernel as slow as its longest tile.
 constexpr int BWD_SEG = 256;                 // = the staging round of the blend forward
-struct BinLayout { size_t point_list, words, quad_hits, inst_gid, inst_grad, seg_list, ckpt, total; };
+struct BinLayout { size_t point_list, words, quad_hits, inst_gid, inst_grad, seg_list, ckpt, list_gid, total; };
 __host__ __device__ inline BinLayout bin_layout(long long R) {
     // point_list sits at offset 0: the tile-sorted list of EMISSION slots e; inst_gid[e] is the Gaussian and
     // inst_grad[e] the slot the blend backward writes that instance's nine partial sums to (one plain 48-byte
@@ -188,6 +188,10 @@ __host__ __device__ inline BinLayout bin_layout(long long R) {
     const size_t nseg = Rz / BWD_SEG + 2;                       // sum over the tiles of (length - 1) / BWD_SEG <= R / BWD_SEG
     L.seg_list = o;   o += align_up(nseg * 8);                  // uint2 {tile, segment}
     L.ckpt = o;       o += align_up(nseg * TILE_PIX * 16);       // float4 per pixel of the tile and listed segment
+    // the Gaussian of every LIST POSITION (= inst_gid[point_list[pos]], written by the per-bin sort as it writes the list): the
+    // blend kernels stage a round through list -> record instead of list -> slot -> Gaussian -> record -- one dependent gather
+    // less per round, and a 4-byte gather from a 64-byte sector less per instance and kernel (round 6)
+    L.list_gid = o;   o += align_up(Rz * 4);
     L.total = o;
     return L;
 }
@@ -385,7 +389,7 @@ struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtua
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
                         const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
-                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
+                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint32_t* list_gid, uint2* ranges,
                         long long bin_bound_hint, TileBinTimes* t, uint32_t* clear_words, uint32_t n_clear, hipStream_t s);
 
 // Diagnostic tuning knobs (lr_tune_set in api.hip): kernel variants that can be switched at run time so that two of them
@@ -429,7 +433,7 @@ __device__ __forceinline__ int blend_tile(int map, int num_tiles)
     return t < num_tiles ? t : -1;
 }
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
-                       const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
+                       const uint32_t* list_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
                        GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final,
                        long long inst_hint, hipStream_t s);

@@ -271,7 +271,7 @@ __device__ __forceinline__ void render_bwd_item(const int tile, const int seg, c
     if (seg_lo >= seg_hi) return;
     // R-dependent parts of the binning buffer, resolved on the device (the host does not know R here)
     const BinLayout BL = bin_layout((long long)hdr->bin_bound);
-    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
+    const uint32_t* __restrict__ list_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.list_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
     const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
     const float4* __restrict__ ck = reinterpret_cast<const float4*>(bin_base + BL.ckpt) + (size_t)ck_slot * TILE_PIX;
@@ -344,7 +344,7 @@ __device__ __forceinline__ void render_bwd_item(const int tile, const int seg, c
         if (tid < cnt) {
             const uint32_t e = point_list[range.x + (pos_hi - tid)];     // emission index of this instance
             s_hit[tid] = quad_hits[range.x + (pos_hi - tid)];
-            const uint32_t id = inst_gid[e];
+            const uint32_t id = list_gid[range.x + (pos_hi - tid)];      // its Gaussian (BinLayout::list_gid: no gather through e)
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             // as render_fwd.hip: scaled exponent coefficients, or the raw conic in strict mode
@@ -489,7 +489,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
     const int seg_hi = seg < 0 ? total : min(total, seg_lo + BWD_SEG);
     if (seg_lo >= seg_hi) return;
     const BinLayout BL = bin_layout((long long)hdr->bin_bound);
-    const uint32_t* __restrict__ inst_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.inst_gid);
+    const uint32_t* __restrict__ list_gid = reinterpret_cast<const uint32_t*>(bin_base + BL.list_gid);
     float4* __restrict__ inst_grad = reinterpret_cast<float4*>(bin_base + BL.inst_grad);
     const uint32_t* __restrict__ quad_hits = reinterpret_cast<const uint32_t*>(bin_base + BL.quad_hits);
     const float4* __restrict__ ck = reinterpret_cast<const float4*>(bin_base + BL.ckpt) + (size_t)ck_slot * TILE_PIX;
@@ -553,7 +553,7 @@ __device__ __forceinline__ void render_bwd_tile(const int tile, const int seg, c
         if (lv < cnt) {
             const uint32_t e = point_list[range.x + (pos_hi - lv)];
             my_hit = quad_hits[range.x + (pos_hi - lv)];
-            const uint32_t id = inst_gid[e];
+            const uint32_t id = list_gid[range.x + (pos_hi - lv)];       // (BinLayout::list_gid: no gather through e)
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             s_q0[lv] = STRICT ? make_float4(a.x, a.y, a.z, a.w) : make_float4(a.x, a.y, (-0.5f * LOG2E) * a.z, -LOG2E * a.w);

@@ -99,7 +99,7 @@ constexpr int PAIR_MIN_LIST = 1024;
 template <bool STRICT, bool PAIR>
 __global__ void __launch_bounds__(THREADS)
 k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
-             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
+             const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ list_gid,
              const GaussRec* __restrict__ rec,
              const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
              float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
@@ -156,7 +156,7 @@ k_render_fwd(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __r
             n_ck++;
         }
         if (tid < cnt) {
-            const uint32_t id = inst_gid[point_list[range.x + base + tid]];   // list holds emission indices
+            const uint32_t id = list_gid[range.x + base + tid];               // the Gaussian of the list position (BinLayout::list_gid)
             const float4* g = reinterpret_cast<const float4*>(rec + id);
             const float4 a = g[0], b = g[1], c = g[2];
             // default: Ap, Bp, Cp and the cull threshold scaled by log2(e); strict: the conic and the threshold as they are
@@ -266,7 +266,7 @@ constexpr int TSTAGE = 64;
 template <bool STRICT>
 __device__ __forceinline__ void
 render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,
-                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,
+                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ list_gid,
                   const GaussRec* __restrict__ rec,
                   const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,
                   float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,
@@ -313,13 +313,13 @@ render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* 
     // (positions beyond the list's end re-read its last entry, never staged).  Fetching the records ahead as well -- into
     // registers: the compiler waits for them where they are issued; straight into a second set of LDS planes with
     // global_load_lds_dwordx4: correct, 6 instead of 7 waves per SIMD -- measured no faster (profiles/r05w_ab_fwd_tile.json).
-    const uint32_t* __restrict__ plist = point_list + range.x;
-    uint32_t id_next = total > 0 ? inst_gid[plist[min(l, total - 1)]] : 0u;
+    const uint32_t* __restrict__ lgid = list_gid + range.x;            // the Gaussian of every list position (BinLayout::list_gid)
+    uint32_t id_next = total > 0 ? lgid[min(l, total - 1)] : 0u;
     for (int base = 0; base < total; base += TSTAGE) {
         if ((done[0] & done[1] & done[2] & done[3]) == ~0ull) break;
         const int cnt = min(TSTAGE, total - base);
         const uint32_t id = id_next;
-        if (base + TSTAGE < total) id_next = inst_gid[plist[min(base + TSTAGE + l, total - 1)]];
+        if (base + TSTAGE < total) id_next = lgid[min(base + TSTAGE + l, total - 1)];
         if (base > 0 && base % BWD_SEG == 0) {
             // (a quadrant whose pixels are all done stopped in front of this position: the backward starts those from final_T)
 #pragma unroll
@@ -400,13 +400,13 @@ render_fwd_tile(int W, int H, int gx, int num_tiles, int tile_map, const uint2* 
     }
 }
 #define LR_FWD_TILE_PARAMS int W, int H, int gx, int num_tiles, int tile_map, const uint2* __restrict__ ranges,                 \
-                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ inst_gid,                              \
+                  const uint32_t* __restrict__ point_list, const uint32_t* __restrict__ list_gid,                              \
                   const GaussRec* __restrict__ rec,                                                                            \
                   const float* __restrict__ bg, float* __restrict__ final_T, uint32_t* __restrict__ n_contrib,                 \
                   float* __restrict__ out_color, float* __restrict__ out_depth, uint8_t* __restrict__ quad_hits,               \
                   GeomHeader* __restrict__ hdr, uint2* __restrict__ seg_list, float4* __restrict__ ckpt,                       \
                   uint32_t* __restrict__ tile_seg0, float4* __restrict__ c_final
-#define LR_FWD_TILE_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color,  \
+#define LR_FWD_TILE_PASS W, H, gx, num_tiles, tile_map, ranges, point_list, list_gid, rec, bg, final_T, n_contrib, out_color,  \
                   out_depth, quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
 // 64 registers -> 8 waves per SIMD: the 8160 tiles of a 1080p view are all resident at once, as in the backward's TILE shape
 // (round 6; with the compiler's own budget, 66-72 registers and 7 waves per SIMD, the last 992 waves waited for the first 7168:
@@ -422,7 +422,7 @@ k_render_fwd_tile(LR_FWD_TILE_PARAMS)
 }  // namespace
 
 void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const uint32_t* point_list,
-                       const uint32_t* inst_gid, const GaussRec* rec, const float* bg, float* final_T,
+                       const uint32_t* list_gid, const GaussRec* rec, const float* bg, float* final_T,
                        uint32_t* n_contrib, float* out_color, float* out_depth, uint8_t* quad_hits,
                        GeomHeader* hdr, uint2* seg_list, float4* ckpt, uint32_t* tile_seg0, float4* c_final,
                        long long inst_hint, hipStream_t s)
@@ -452,7 +452,7 @@ void launch_render_fwd(int W, int H, int gx, int gy, const uint2* ranges, const 
 #endif
     const bool strict = tune_get(TUNE_STRICT) > 0;
     note_fwd_shape(tile_shape ? 2 : pair ? 1 : 0);
-#define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, inst_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
+#define LR_FWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, list_gid, rec, bg, final_T, n_contrib, out_color, out_depth, \
                     quad_hits, hdr, seg_list, ckpt, tile_seg0, c_final
     if (tile_shape) {
         if (strict) hipLaunchKernelGGL((k_render_fwd_tile<true>), dim3(grid), dim3(64), 0, s, LR_FWD_ARGS);

@@ -494,12 +494,15 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* a, uint32_t n, 
 // after the sort: the list entries (slots) and, when a bin holds several tiles, the per-tile ranges
 __device__ __forceinline__ void write_sorted(const unsigned long long* a, uint32_t n, uint32_t start, int bin, int sub_shift,
                                              int slot_bits, int num_tiles, uint32_t tid, uint32_t nthreads,
-                                             uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+                                             uint32_t* __restrict__ point_list, uint2* __restrict__ ranges,
+                                             const uint32_t* __restrict__ inst_gid, uint32_t* __restrict__ list_gid)
 {
     const unsigned long long slot_mask = (1ull << slot_bits) - 1ull;
     for (uint32_t i = tid; i < n; i += nthreads) {
         const unsigned long long w = a[i];
-        point_list[start + i] = (uint32_t)(w & slot_mask);
+        const uint32_t slot = (uint32_t)(w & slot_mask);
+        point_list[start + i] = slot;
+        list_gid[start + i] = inst_gid[slot];       // the Gaussian of the list position (common.h BinLayout::list_gid)
         if (sub_shift != 0) {
             const uint32_t sub = (uint32_t)(w >> (31 + slot_bits));
             const int tile = (bin << sub_shift) + (int)sub;
@@ -612,7 +615,8 @@ __device__ __forceinline__ void bucket_sort_bin(const unsigned long long* __rest
 __global__ void __launch_bounds__(256)
 k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_tiles, int bucket_b, const uint32_t* __restrict__ bin_start,
                   const uint32_t* __restrict__ bin_total, const unsigned long long* __restrict__ words,
-                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges)
+                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ inst_gid,
+                  uint32_t* __restrict__ list_gid)
 {
     __shared__ unsigned long long s_a[4 * TSORT_LDS];         // 4 x 256 entries = TSORT_GROUP_LDS
     __shared__ uint32_t s_cnt[TSORT_GROUP_LDS];               // part B's bucket counters
@@ -636,13 +640,13 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
             // profiles/r04d_ab_tsort_wave.json); up to 64 entries the network's 21 stages stay cheaper
             bucket_sort_bin<64, TSORT_LDS / 64>(words + start, n, slot_bits, a, s_cnt + w * TSORT_LDS, s_red + 2 * w, s_wave + w,
                                                 &s_bad[w], l, wsync);
-            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges);
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges, inst_gid, list_gid);
             return;
         }
         for (uint32_t i = l; i < n; i += 64) a[i] = words[start + i];
         wsync();
         if (n > 1) bitonic_sort(a, n, (uint32_t)l, 64u, wsync);
-        write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges);
+        write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)l, 64u, point_list, ranges, inst_gid, list_gid);
         return;
     }
     // part B: the remaining workgroups walk the bins with a stride and take those of 257..1024 entries, one at a time, with
@@ -663,7 +667,7 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
             lds_barrier();
             bitonic_sort(s_a, n, threadIdx.x, 256u, [] { lds_barrier(); });
         }
-        write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges);
+        write_sorted(s_a, n, start, bin, sub_shift, slot_bits, num_tiles, threadIdx.x, 256u, point_list, ranges, inst_gid, list_gid);
     }
 }
 
@@ -677,7 +681,8 @@ k_tile_sort_small(int bins, int groups4, int sub_shift, int slot_bits, int num_t
 __global__ void __launch_bounds__(TSORT_THREADS)
 k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entries, const uint32_t* __restrict__ bin_start,
                   const uint32_t* __restrict__ bin_total, unsigned long long* __restrict__ words,
-                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue)
+                  uint32_t* __restrict__ point_list, uint2* __restrict__ ranges, const uint32_t* __restrict__ big_queue,
+                  const uint32_t* __restrict__ inst_gid, uint32_t* __restrict__ list_gid)
 {
     constexpr int PER = TSORT_MID_LDS / TSORT_THREADS;                // 8 items / buckets per thread
     extern __shared__ unsigned long long s_out[];                     // [max(TSORT_MID_LDS, lds_entries)]
@@ -697,18 +702,18 @@ k_tile_sort_large(int sub_shift, int slot_bits, int num_tiles, uint32_t lds_entr
             for (uint32_t i = tid; i < n; i += TSORT_THREADS) s_out[i] = words[start + i];
             lds_barrier();
             bitonic_sort(s_out, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { lds_barrier(); });
-            write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+            write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges, inst_gid, list_gid);
         } else {
             // larger than the LDS of this launch: the same network in place in global memory (one workgroup, L2-resident;
             // slow, but a single tile with that many splats is slow to blend anyway)
             unsigned long long* a = words + start;
             bitonic_sort(a, n, (uint32_t)tid, (uint32_t)TSORT_THREADS, [] { __threadfence(); lds_barrier(); });
-            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+            write_sorted(a, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges, inst_gid, list_gid);
         }
         continue;
     }
     bucket_sort_bin<TSORT_THREADS, PER>(words + start, n, slot_bits, s_out, s_cnt, s_red, s_wave, &s_bad, tid, [] { lds_barrier(); });
-    write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges);
+    write_sorted(s_out, n, start, bin, sub_shift, slot_bits, num_tiles, (uint32_t)tid, (uint32_t)TSORT_THREADS, point_list, ranges, inst_gid, list_gid);
     }
 }
 
@@ -735,7 +740,7 @@ void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sum
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,
                         const uint4* hitrec, const GaussRec* rec, const int* radii, GeomHeader* hdr,
                         uint32_t* part_hist, uint32_t* bin_total, uint32_t* bin_start, uint32_t* big_queue,
-                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint2* ranges,
+                        uint32_t* inst_gid, unsigned long long* words, uint32_t* point_list, uint32_t* list_gid, uint2* ranges,
                         long long bin_bound_hint, TileBinTimes* t, uint32_t* clear_words, uint32_t n_clear, hipStream_t s)
 {
     // the partition kernels keep one counter per bin in LDS (up to 64 KB), the large-bin sort up to 128 KB.  The attribute is
@@ -797,7 +802,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     // bitonic network), 0 = the network for everything up to 1024 (lr_tune_set("tsort", v): A/B runs)
     const int bucket_b = tune_get(TUNE_TSORT) >= 0 ? tune_get(TUNE_TSORT) : 2;
     hipLaunchKernelGGL(k_tile_sort_small, dim3(groups4 + part_b), dim3(256), 0, s, pp.bins, groups4, pp.sub_shift, slot_bits,
-                       num_tiles, bucket_b, bin_start, bin_total, words, point_list, ranges);
+                       num_tiles, bucket_b, bin_start, bin_total, words, point_list, ranges, inst_gid, list_gid);
     // the large bins: LDS for the bucket sort (32 KB of words; three workgroups per CU) unless the AVERAGE bin is already
     // beyond it -- then 128 KB, so that bins of up to 16384 entries are sorted in LDS (a hint for speed only: a bin that
     // does not fit this launch's LDS is sorted in place in global memory).  Capped grid: a sparse view queues nothing
@@ -810,7 +815,7 @@ int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vi
     const int large_cap = huge ? TSORT_BIG_BLOCKS : (avg_bin <= (long long)TSORT_LDS ? TSORT_LARGE_BLOCKS / 12 : TSORT_LARGE_BLOCKS);
     const int large_blocks = pp.bins < large_cap ? pp.bins : large_cap;
     hipLaunchKernelGGL(k_tile_sort_large, dim3(large_blocks), dim3(TSORT_THREADS), (size_t)lds_entries * 8, s, pp.sub_shift,
-                       slot_bits, num_tiles, lds_entries, bin_start, bin_total, words, point_list, ranges, big_queue);
+                       slot_bits, num_tiles, lds_entries, bin_start, bin_total, words, point_list, ranges, big_queue, inst_gid, list_gid);
     if (t) t->mark(4, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;        // a refused launch (LDS attribute, grid) surfaces here, not at the blend
 }
