@@ -402,7 +402,7 @@ int tune_get(int key);
 // BLEND_TILE = one wave per tile, four pixels per lane (issue bound: the per-candidate reduction is paid once per tile).
 // LR_BLEND_QUAD_BWD=0/1/2 or lr_tune_set("blend_quad", .) forces one (diagnostics).
 enum { BLEND_HALF = 0, BLEND_QUAD = 1, BLEND_TILE = 2 };
-int blend_shape(int num_tiles);
+int blend_shape(int num_tiles, long long inst_bound = -1);
 // Host-side hint: how many views' kernels the caller keeps in flight on different streams (lr_views_accumulate sets it for
 // its own duration; a caller that pipelines the per-view entry points itself -- parallel.ViewStreams -- passes it through
 // lr_tune_set("views_in_flight", n)).  Never a correctness input: it picks between kernel shapes with identical results.

@@ -777,7 +777,7 @@ ViewsInFlight::ViewsInFlight(int n) : prev(g_views_in_flight) { g_views_in_fligh
 ViewsInFlight::~ViewsInFlight() { g_views_in_flight = prev; }
 int views_in_flight() { return max(g_views_in_flight, tune_get(TUNE_VIEWS_IN_FLIGHT)); }
 
-int blend_shape(int num_tiles)
+int blend_shape(int num_tiles, long long inst_bound)
 {
     static const int forced = env_knob("LR_BLEND_QUAD_BWD");
     if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD);
@@ -792,8 +792,11 @@ int blend_shape(int num_tiles)
     //     2 / 1 waves; dense 1 M cloud: the three within 2 %), but with other views in flight the chains overlap anyway and the
     //     shape that issues the fewest instructions wins: dense 1 M cloud at 512^2 1967 (1 wave) / 1917 (2) / 1787 (4) views/s,
     //     pixel-sized splats 5960 / 6020 / 5800.
+    //     A lone view of LONG lists (more than 1024 instances per tile by the bound the caller passes: the dense cloud) is the
+    //     one case left to the 2-wave shape: 1410-1430 against 1380-1410 (4 waves) / 1400 (1 wave) views/s.
     if (num_tiles > 3072) return BLEND_TILE;
-    return views_in_flight() >= 2 ? BLEND_TILE : BLEND_QUAD;
+    if (views_in_flight() >= 2) return BLEND_TILE;
+    return inst_bound > 1024ll * num_tiles ? BLEND_HALF : BLEND_QUAD;
 }
 
 // shapes of the process's last blend launches (lr_last_launch_shapes: tests assert which kernels a configuration ran; process-wide,
@@ -826,7 +829,8 @@ void launch_render_bwd(int W, int H, int gx, int gy, const uint2* ranges, const 
     constexpr int pad = 0;
 #endif
 #define LR_BWD_ARGS W, H, gx, num_tiles, tile_map, ranges, point_list, rec, bg, final_T, n_contrib, dL_dpix, bin_base, hdr, force_check
-    int shape = blend_shape(num_tiles);
+    // instances the caller's bound allows (bin_seg_capacity(bound) = bound / BWD_SEG + 2): an upper estimate of the lists' lengths
+    int shape = blend_shape(num_tiles, seg_bound > 2 ? (seg_bound - 2) * (long long)BWD_SEG : -1);
     const bool strict = tune_get(TUNE_STRICT) > 0;
     // Segments (common.h BWD_SEG): on by default; lr_tune_set("bwd_seg", 0) = one workgroup walks a tile's whole list (rounds
     // 1-4: what the segment tests compare with).  The launch adds workgroups for the listed segments up to the bound the host

@@ -22,20 +22,27 @@ def test_the_rule_picks_a_shape_within_3_percent_of_the_best(hip_device, name, v
     args = argparse.Namespace(sh_degree=3, no_fused_accumulate=False, gaussians=None, exchange="allreduce")
     wl = bench.Workload(name, args, 0, 1, hip_device, views=views)
     combos = [(-1, -1), (0, -1), (1, -1), (2, -1), (-1, 0), (-1, 2)]          # the rule; each backward shape; each forward shape
-    best = {}
+    best, shapes = {}, {}
     try:
-        for _ in range(3):
-            for b, f in combos:
+        for rnd in range(3):
+            order = combos[rnd * 2:] + combos[:rnd * 2]                        # no configuration is always the first of a round
+            for b, f in order:
                 _lib.tune_set("blend_quad", b)
                 _lib.tune_set("fwd_pair", f)
-                v, _, _, _ = bench.run_leg(wl, "views", False, in_flight, 4, 1, 1, hip_device)
+                v, _, _, _ = bench.run_leg(wl, "views", False, in_flight, 5, 2, 1, hip_device)
                 best[(b, f)] = max(best.get((b, f), 0.0), v)
+                shapes[(b, f)] = _lib.last_launch_shapes()
     finally:
         _lib.tune_set("blend_quad", -1)
         _lib.tune_set("fwd_pair", -1)
         config.reset()
         del wl
         torch.cuda.empty_cache()
+    # a forced configuration that launched the very kernels the rule picks IS the rule: its measurements count for the rule
+    # (two legs of identical kernels differ by up to 2 % on this part: the figure compared must not be noise between the two)
+    for k in list(best):
+        if k != (-1, -1) and shapes[k] == shapes[(-1, -1)]:
+            best[(-1, -1)] = max(best[(-1, -1)], best[k])
     rule = best.pop((-1, -1))
     top = max(best.values())
     print(f"{name} {in_flight} in flight: rule {rule:.1f} views/s, best forced {top:.1f} ({max(best, key=best.get)}), ratio {rule / top:.3f}")
