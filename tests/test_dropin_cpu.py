@@ -153,3 +153,36 @@ def test_visibility_filter_keeps_the_masked_max_radii_update_on_the_device_and_i
     src.add_(1.0)
     with pytest.raises(RuntimeError, match="changed in place"):
         held.sum()
+
+
+def test_plain_iteration_follows_the_reference_loop_schedule():
+    """install(fuse_step=True) arms the optimizer on exactly the iterations on which the reference's loop
+    (R/luciddreamer.py:305-327) runs loss.backward() and optimizer.step() back to back on an unchanged parameter set.  The
+    predicate against a literal walk through that loop's control flow, for the reference's own GSParams and three variations."""
+    import types
+    from luciddreamer_amd.dropin import plain_iteration
+
+    def walk(a, iteration):
+        """(did the loop touch the parameter set before the step, did it step) as luciddreamer.py:305-327 decides them"""
+        touched = False
+        if iteration < a.densify_until_iter:
+            if iteration > a.densify_from_iter and iteration % a.densification_interval == 0:
+                touched = True                                   # densify_and_prune
+            if iteration % a.opacity_reset_interval == 0 or (a.white_background and iteration == a.densify_from_iter):
+                touched = True                                   # reset_opacity
+        stepped = iteration < a.iterations
+        return touched, stepped
+
+    base = dict(iterations=2990, densify_until_iter=15_000, densify_from_iter=500, densification_interval=100,
+                opacity_reset_interval=3000, white_background=False)
+    for change in ({}, {"white_background": True}, {"densify_until_iter": 1200, "opacity_reset_interval": 700},
+                   {"iterations": 301, "densify_from_iter": 5, "densification_interval": 10}):
+        a = types.SimpleNamespace(**dict(base, **change))
+        armed = 0
+        for it in range(1, a.iterations + 1):
+            touched, stepped = walk(a, it)
+            assert plain_iteration(a, it) == (stepped and not touched), (change, it)
+            armed += plain_iteration(a, it)
+        assert 0 < armed < a.iterations
+    # a training_args object without the schedule's fields never arms
+    assert not plain_iteration(types.SimpleNamespace(iterations=10), 3)
