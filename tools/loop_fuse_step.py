@@ -46,7 +46,7 @@ for scene in a.scene.split(","):
     order = [int(i) for i in np.random.default_rng(9).integers(0, 8, size=a.iters)]
     for mode in a.modes.split(","):
         config.reset()
-        config.set_async(True)
+        config.set_async(True, on_overflow=os.environ.get("LR_POLICY", "verify"))
         best, vis = None, None
         for p in range(a.passes + 1):
             with ref_loop.stack("ours") as (R, dev):
