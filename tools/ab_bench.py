@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """A/B measurement of kernel variants inside ONE process on ONE box (lr_tune_set switches them at run time).
 
-    python tools/ab_bench.py --knob bwd_red --values 0,1,2,3,4 [--workloads c3,c3box] [--rounds 3] [--steps 5]
+    python tools/ab_bench.py --knob blend_quad --values=-1,0,2 [--workloads c3,c3box] [--rounds 3] [--steps 5] [--also fwd_pair=0]
+    tools/diag_env.sh python tools/ab_bench.py --knob bwd_red --values=-1,2 --also blend_quad=2      # a RETIRED kernel as partner:
+                                                                   # diagnostics build (python -m luciddreamer_amd.build --diagnostics)
 
 For every workload and every value of the knob, `rounds` alternated measurements of
   * the single-stream per-stage times (HIP events inside the library, bench.py's roofline leg), and
