@@ -783,7 +783,7 @@ int blend_shape(int num_tiles, long long inst_bound)
     if (tune_get(TUNE_BLEND_QUAD) >= 0) return tune_get(TUNE_BLEND_QUAD);
     if (forced >= 0) return forced;
     // Round 6 rule, from tools/shape_sweep.py on the final kernels (profiles/r06q_shape_sweep.json: every forced pair of
-    // forward / backward shapes on six workloads, three views in flight and one; tests/test_gpu_heuristics.py keeps it honest):
+    // forward / backward shapes on six workloads, three views in flight and one; tests/test_gpu_zz_heuristics.py keeps it honest):
     //   * large images (> 3072 tiles): one wave per tile.  Since its reduction goes through LDS and it no longer spills (round 6)
     //     it beats the 2-wave shape also for a lone view: C2 +5 %, C3 +1.5 %, dense 1080p +6.8 %, 3 M / 1440p +3.3 % views/s
     //     (three views in flight: +3 ... +8 %).  [Rounds 4-5 picked the 2-wave shape for a lone view.]

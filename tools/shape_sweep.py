@@ -5,7 +5,7 @@ tile), with three views in flight (the multi-view entry points) and with one (a 
 
     python tools/shape_sweep.py [--workloads c2,c3,c3box,c4shape,c5shape,ld512] [--steps 6] [--rounds 2] [--out gpurun_out/shape_sweep.json]
 
-tests/test_gpu_heuristics.py asserts the same on a reduced sweep."""
+tests/test_gpu_zz_heuristics.py asserts the same on a reduced sweep."""
 import argparse
 import json
 import os
