@@ -232,7 +232,7 @@ def add_densification_stats(model, viewspace_point_tensor, radii):
         raise RuntimeError("add_densification_stats needs contiguous float32 statistics / gradient and int32 radii on a HIP device")
     L = _lib.lib()
     dev = radii.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         rc = L.lr_densify_stats(P, radii.data_ptr(), g.data_ptr(), model.xyz_gradient_accum.data_ptr(), model.denom.data_ptr(),
                                 model.max_radii2D.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc < 0:

@@ -28,7 +28,7 @@ class _L1DSSIM(torch.autograd.Function):
         dev = x.device
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
         ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), float(lambda_dssim), out3.data_ptr(),
                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:
@@ -46,7 +46,7 @@ class _L1DSSIM(torch.autograd.Function):
         dev = x.device
         up = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
         grad = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.lr_l1_dssim_backward(C, H, W, x.data_ptr(), g.data_ptr(), ctx.lam, up.data_ptr(), ws.data_ptr(),
                                         grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:
@@ -89,7 +89,7 @@ class _L1SSIMPair(torch.autograd.Function):
         dev = x.device
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
         ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), 0.0, out3.data_ptr(), ws.data_ptr(), ws.numel(),
                                        torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:
@@ -107,7 +107,7 @@ class _L1SSIMPair(torch.autograd.Function):
         as_w = lambda t: (torch.zeros(1, device=dev) if t is None else t.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous())
         w1, w2 = as_w(g_l1), as_w(g_ssim)
         grad = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = L.lr_l1_dssim_backward_weights(C, H, W, x.data_ptr(), g.data_ptr(), w1.data_ptr(), w2.data_ptr(), ws.data_ptr(),
                                                 grad.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
         if rc < 0:

@@ -110,7 +110,7 @@ class FusedAdam(torch.optim.Optimizer):
         for st in states:
             st["step"] += 1
         b1, b2 = groups[0]["betas"]
-        with torch.cuda.device(params[0].device):
+        with _lib.on_device(params[0].device):
             _C.adam_step_masked(list(params), list(bufs), [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
                                 [float(g["lr"]) for g in groups], float(b1), float(b2), float(groups[0]["eps"]), steps.pop() + 1, geom)
         return set(id(p) for p in params)
@@ -167,7 +167,7 @@ class FusedAdam(torch.optim.Optimizer):
                 arr = lambda k: (ctypes.c_void_p * n)(*[it[k].data_ptr() for it in chunk])
                 numel = (ctypes.c_ulonglong * n)(*[it[0].numel() for it in chunk])
                 lrs = (ctypes.c_double * n)(*[it[4] for it in chunk])
-                with torch.cuda.device(dev):
+                with _lib.on_device(dev):
                     rc = L.lr_adam_step(n, arr(0), arr(1), arr(2), arr(3), numel, lrs, float(b1), float(b2), float(eps),
                                         int(step), torch.cuda.current_stream(dev).cuda_stream)
                 if rc < 0:
