@@ -35,7 +35,7 @@ class FusedAdam(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
-        self._fused_pending = None       # (geom buffer, params, their gradient tensors -- visited rows only) of an armed backward
+        self._fused_pending = None       # the parameters an armed backward has already stepped, until step() has checked the iteration
 
     # ---- the step taken by the backward pass (lr_backward_raw_adam) ------------------------------------------
     def _fused_groups(self):
@@ -65,8 +65,9 @@ class FusedAdam(torch.optim.Optimizer):
         """The NEXT raw-mode rasterizer backward over exactly this optimizer's six GaussianModel tensors (groups named
         xyz / f_dc / f_rest / opacity / scaling / rotation, one tensor each) hands its gradients to this optimizer PRIVATELY:
         it writes only the rows of the Gaussians the view visits into tensors the optimizer keeps until step() (no zero-fill of the other rows:
-        LR_ACC_NO_ZERO_FILL) and returns no gradient to autograd -- param.grad stays None -- and the step() that follows runs
-        lr_adam_step_masked, which takes the gradient of an unvisited Gaussian as zero without reading it.  Gone per iteration:
+        LR_ACC_NO_ZERO_FILL), returns no gradient to autograd -- param.grad stays None -- and launches lr_adam_step_masked right
+        behind its own kernels (apply_armed_step: the step takes the gradient of an unvisited Gaussian as zero without reading
+        it); the step() that follows only checks the iteration.  Gone per iteration:
         the zero-fill pass over 236 B per Gaussian, the read of those zeros, the allocation of six gradient tensors.
         Parameters and moments after the pair are bit-identical to backward + step().  For a loop in which EVERY armed backward
         is followed by exactly one step() with no other gradient source and no change of the parameter set in between
@@ -91,17 +92,14 @@ class FusedAdam(torch.optim.Optimizer):
         if _armed is self:
             _armed = None
 
-    def _finish_fused(self):
+    def apply_armed_step(self, geom, params, grads):
+        """Called by the rasterizer's backward right after it has enqueued the armed backward's kernels: the masked step is
+        launched HERE, from inside loss.backward(), not when the loop reaches optimizer.step() -- on a LucidDreamer-sized view the
+        host needs ~130 us for the loop's own lines between the two (the max-radii update, the densification statistics, the
+        step's Python), during which the GPU would wait for the 290 us Adam kernel to arrive; step() then only checks that the
+        iteration went as an armed iteration must.  Nothing in between reads the parameters (the statistics read dL/dmeans2D and
+        the radii), and iterations that densify or reset opacities are never armed."""
         from . import _C
-        geom, params, bufs = self._fused_pending
-        self._fused_pending = None
-        now = self._fused_params()
-        if now is None or any(a is not b for a, b in zip(now, params)):
-            raise RuntimeError("FusedAdam.step: the parameter set changed between an armed backward and step(): its gradients belong "
-                               "to the old tensors; do not arm iterations that densify / prune / replace tensors")
-        if any(p.grad is not None for p in params):
-            raise RuntimeError("FusedAdam.step: a parameter received a .grad while an armed backward's gradients were pending (a "
-                               "second backward, or another loss term): the two cannot be combined; do not arm such iterations")
         groups = self._fused_groups()
         states = [self._state_of(p) for p in params]
         steps = {int(st["step"].item()) for st in states}
@@ -110,9 +108,22 @@ class FusedAdam(torch.optim.Optimizer):
         for st in states:
             st["step"] += 1
         b1, b2 = groups[0]["betas"]
-        with _lib.on_device(params[0].device):
-            _C.adam_step_masked(list(params), list(bufs), [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
+        with _lib.on_device(params[0].device), torch.no_grad():
+            _C.adam_step_masked(list(params), list(grads), [st["exp_avg"] for st in states], [st["exp_avg_sq"] for st in states],
                                 [float(g["lr"]) for g in groups], float(b1), float(b2), float(groups[0]["eps"]), steps.pop() + 1, geom)
+        self._fused_pending = list(params)
+
+    def _finish_fused(self):
+        params = self._fused_pending
+        self._fused_pending = None
+        now = self._fused_params()
+        if now is None or any(a is not b for a, b in zip(now, params)):
+            raise RuntimeError("FusedAdam.step: the parameter set changed between an armed backward and step() -- the step has "
+                               "already been taken on the old tensors; do not arm iterations that densify / prune / replace tensors")
+        if any(p.grad is not None for p in params):
+            raise RuntimeError("FusedAdam.step: a parameter received a .grad after an armed backward had taken this iteration's step "
+                               "(a second backward, or another loss term): that gradient cannot be applied any more; do not arm "
+                               "such iterations")
         return set(id(p) for p in params)
 
     def zero_grad(self, set_to_none: bool = True):

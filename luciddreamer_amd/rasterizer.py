@@ -228,9 +228,10 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             g_dc, g_rest = leaf_grad(li["features_dc"]), leaf_grad(li["features_rest"])
             if g_dc is not None and (g_rest is not None or features_rest.numel() == 0):
                 accumulate_into["features"] = (g_dc, g_rest)
-        # an armed FusedAdam over exactly these six tensors (optim.FusedAdam.arm_fused_backward): the gradients go to buffers the
-        # optimizer keeps -- visited rows only, nothing zero-filled -- and its step() reads them through the view's own
-        # visibility (lr_adam_step_masked).  Autograd gets no parameter gradient: param.grad stays None.
+        # an armed FusedAdam over exactly these six tensors (optim.FusedAdam.arm_fused_backward): the gradients go to tensors
+        # autograd never sees -- visited rows only, nothing zero-filled -- and the optimizer's masked step
+        # (lr_adam_step_masked: the view's own visibility is the mask) is launched right behind the backward's kernels;
+        # optimizer.step() later only checks the iteration.  param.grad stays None.
         from . import optim
         opt = optim.take_armed((xyz, features_dc, features_rest, opacity, scaling, rotation)) \
             if (optim._armed is not None and not rs.debug and all(ctx.needs_input_grad[k] for k in (0, 2, 4, 5, 6))) else None
@@ -239,7 +240,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
                 rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
                 rs.projmatrix, rs.tanfovx, rs.tanfovy, grad_out_color, rs.sh_degree, rs.campos, geom, ctx.num_rendered,
                 binning, img, False, binning_capacity=ctx.binning_capacity, no_zero_fill=True)
-            opt._fused_pending = (geom, [xyz, features_dc, features_rest, opacity, scaling, rotation], list(g[1:]))
+            opt.apply_armed_step(geom, [xyz, features_dc, features_rest, opacity, scaling, rotation], list(g[1:]))
             return None, g[0], None, None, None, None, None, None
         g = _C.rasterize_gaussians_raw_backward(
             rs.bg, xyz, radii, features_dc, features_rest, opacity, scaling, rotation, rs.scale_modifier, rs.viewmatrix,
