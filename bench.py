@@ -1070,9 +1070,10 @@ def run_cpu_baseline(wl):
                     ("verify", "this_rasterizer_after_install",
                      "the same unchanged loop after luciddreamer_amd.install(reference modules): one call, no edits to the caller", None),
                     ("verify", "this_rasterizer_after_install_fuse_step",
-                     "the same after install(reference modules, fuse_step=True): the optimizer step of every plain iteration is taken "
-                     "BY its backward pass (the kernel that sums a visible Gaussian's gradient applies Adam to its rows; step() "
-                     "finishes the Gaussians the view did not touch) -- parameters bit-identical to the line above "
+                     "the same after install(reference modules, fuse_step=True): on every plain iteration the backward hands its gradients "
+                     "to the optimizer privately -- visited rows only, no zero-fill (LR_ACC_NO_ZERO_FILL) -- and launches the masked "
+                     "Adam step (lr_adam_step_masked) right behind its own kernels; optimizer.step() only checks the iteration -- "
+                     "parameters bit-identical to the line above "
                      "(tests/test_gpu_optim.py, tests/test_gpu_reference_stack.py)", None),
                     ("drop", "this_rasterizer_after_install_policy_drop",
                      "the same with config.set_async(True, on_overflow='drop'): the forward does not wait for its own header (a view "
