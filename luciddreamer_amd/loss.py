@@ -11,6 +11,25 @@ import torch
 
 from . import _lib
 
+_WS_BYTES = {}                      # (C, H, W) -> lr_loss_workspace_bytes: a C call per forward otherwise
+
+
+def _ws_bytes(L, C, H, W):
+    n = _WS_BYTES.get((C, H, W))
+    if n is None:
+        n = _WS_BYTES[(C, H, W)] = int(L.lr_loss_workspace_bytes(C, H, W))
+    return n
+
+
+def _weight(t, dev):
+    """An upstream gradient as the one-float device tensor the kernels read: as it is when autograd already hands over a float32
+    scalar on the device (the usual case: three tensor ops saved per backward), converted otherwise."""
+    if t is None:
+        return torch.zeros(1, device=dev)
+    if t.dtype is torch.float32 and t.device == dev and t.numel() == 1 and t.is_contiguous():
+        return t
+    return t.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+
 
 class _L1DSSIM(torch.autograd.Function):
     @staticmethod
@@ -27,7 +46,7 @@ class _L1DSSIM(torch.autograd.Function):
         L = _lib.lib()
         dev = x.device
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
-        ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((_ws_bytes(L, C, H, W),), dtype=torch.uint8, device=dev)
         with _lib.on_device(dev):
             rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), float(lambda_dssim), out3.data_ptr(),
                                        ws.data_ptr(), ws.numel(), torch.cuda.current_stream(dev).cuda_stream)
@@ -44,7 +63,7 @@ class _L1DSSIM(torch.autograd.Function):
         C, H, W = ctx.dims
         L = _lib.lib()
         dev = x.device
-        up = grad_out.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous()
+        up = _weight(grad_out, dev)
         grad = torch.empty_like(x)
         with _lib.on_device(dev):
             rc = L.lr_l1_dssim_backward(C, H, W, x.data_ptr(), g.data_ptr(), ctx.lam, up.data_ptr(), ws.data_ptr(),
@@ -88,7 +107,7 @@ class _L1SSIMPair(torch.autograd.Function):
         L = _lib.lib()
         dev = x.device
         out3 = torch.empty((3,), dtype=torch.float32, device=dev)
-        ws = torch.empty((L.lr_loss_workspace_bytes(C, H, W),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((_ws_bytes(L, C, H, W),), dtype=torch.uint8, device=dev)
         with _lib.on_device(dev):
             rc = L.lr_l1_dssim_forward(C, H, W, x.data_ptr(), g.data_ptr(), 0.0, out3.data_ptr(), ws.data_ptr(), ws.numel(),
                                        torch.cuda.current_stream(dev).cuda_stream)
@@ -104,8 +123,7 @@ class _L1SSIMPair(torch.autograd.Function):
         C, H, W = ctx.dims
         L = _lib.lib()
         dev = x.device
-        as_w = lambda t: (torch.zeros(1, device=dev) if t is None else t.detach().to(device=dev, dtype=torch.float32).reshape(1).contiguous())
-        w1, w2 = as_w(g_l1), as_w(g_ssim)
+        w1, w2 = _weight(g_l1, dev), _weight(g_ssim, dev)
         grad = torch.empty_like(x)
         with _lib.on_device(dev):
             rc = L.lr_l1_dssim_backward_weights(C, H, W, x.data_ptr(), g.data_ptr(), w1.data_ptr(), w2.data_ptr(), ws.data_ptr(),
