@@ -381,7 +381,7 @@ void radix_sort_pairs(uint32_t* key_a, uint32_t* key_b, uint32_t* val_a, uint32_
 // nullptr -- the kernel leaves the header there behind `log_tag` (lr_header_poll on a log ticket spins on the tag).
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
-                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, hipStream_t s);
+                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, bool reset_sticky, hipStream_t s);
 // optional per-stage timing hook of launch_tile_binning (api.hip ProfScope events)
 struct TileBinTimes { virtual void mark(int boundary, hipStream_t s) = 0; virtual ~TileBinTimes() {} };
 // count -> scan -> scatter -> per-bin sort: point_list, inst_gid and ranges from the compacted list.  Returns 0, -1

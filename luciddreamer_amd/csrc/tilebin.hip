@@ -74,7 +74,8 @@ __device__ __forceinline__ uint32_t block_reduce_sum(uint32_t v, uint32_t* s_tmp
 __global__ void __launch_bounds__(SCAN_THREADS)
 k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* __restrict__ block_sums,
                 uint32_t* __restrict__ vis_list, uint32_t* __restrict__ offsets, GeomHeader* hdr, uint32_t capacity,
-                uint32_t* __restrict__ log_slot, uint32_t log_tag, uint32_t* __restrict__ zero_words, uint32_t n_zero)
+                uint32_t* __restrict__ log_slot, uint32_t log_tag, uint32_t* __restrict__ zero_words, uint32_t n_zero,
+                int reset_sticky)
 {
     __shared__ uint32_t s_tmp[4];
     // the per-bin cursors of the partition (k_part<0> reserves its ranges on them with atomics): zero before its launch
@@ -140,7 +141,8 @@ k_compact_write(int P, const uint32_t* __restrict__ tiles_touched, const uint4* 
         hdr->num_compact = run_c;
         hdr->n_seg = 0u;                        // the blend forward reserves its list segments on it
         hdr->bwd_uncovered = 0u;
-        if (over) hdr->sticky_overflow = 1u;
+        // sticky across the views of a step on this buffer; the step's first view starts it (api.hip views_core)
+        if (over || reset_sticky) hdr->sticky_overflow = over ? 1u : 0u;
         if (log_slot != nullptr) {
             // the library's forward log (host-visible memory, api.hip ForwardLog): the header words first, the tag last,
             // each with system scope -- the host spins on the tag instead of waiting for a copy and an event
@@ -730,11 +732,11 @@ PartPlan part_plan(int num_tiles)
 
 void launch_compact(int P, const uint32_t* tiles_touched, const uint4* block_sums,
                     uint32_t* vis_list, uint32_t* offsets, GeomHeader* hdr, uint32_t capacity, uint32_t* log_slot,
-                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, hipStream_t s)
+                    uint32_t log_tag, uint32_t* zero_words, uint32_t n_zero, bool reset_sticky, hipStream_t s)
 {
     const int nb = (P + SCAN_TILE - 1) / SCAN_TILE;
     hipLaunchKernelGGL(k_compact_write, dim3(nb), dim3(SCAN_THREADS), 0, s, P, tiles_touched, block_sums, vis_list,
-                       offsets, hdr, capacity, log_slot, log_tag, zero_words, n_zero);
+                       offsets, hdr, capacity, log_slot, log_tag, zero_words, n_zero, reset_sticky ? 1 : 0);
 }
 
 int launch_tile_binning(int P, int gx, int gy, int slot_bits, const uint32_t* vis_list, const uint32_t* offsets,

@@ -83,8 +83,9 @@ AccumulateChain& accumulate_chain(int device)
     std::lock_guard<std::mutex> lock(mu);
     AccumulateChain& c = chains[device];
     if (!c.ev[0]) {
-        (void)hipEventCreateWithFlags(&c.ev[0], hipEventDisableTiming);
-        (void)hipEventCreateWithFlags(&c.ev[1], hipEventDisableTiming);
+        // device-side ordering only (never synchronised with by the host): no system-scope fence at the record
+        (void)hipEventCreateWithFlags(&c.ev[0], hipEventDisableTiming | hipEventDisableSystemFence);
+        (void)hipEventCreateWithFlags(&c.ev[1], hipEventDisableTiming | hipEventDisableSystemFence);
     }
     return c;
 }
