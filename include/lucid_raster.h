@@ -253,8 +253,10 @@ int lr_backward_raw(int P, int D, int M, int R,
  * Runs lr_forward + lr_backward for n_views views of ONE parameter set and ACCUMULATES the gradients into the
  * acc_* buffers (same shapes as lr_backward's outputs; acc_color / acc_cov3D / acc_sh / acc_scale / acc_rot may be
  * NULL when the corresponding input is absent).  Everything is enqueued from C in one call: views alternate over
- * up to 4 internal HIP streams (forward of view i+1 overlaps the backward of view i; the accumulating kernels
- * are chained by events) which are forked from / joined to `stream` with events -- no host synchronisation.
+ * up to 4 chains (forward of view i+1 overlaps the backward of view i; the accumulating kernels are chained by
+ * events): the chain that ends with the last view runs on `stream` itself, the others on streams of the library
+ * which are forked from / joined to `stream` with events -- no host synchronisation; everything the call
+ * enqueued is ordered before whatever is enqueued on `stream` after it.
  * Async mode only (binning_capacity > 0); an overflow of any view is latched per slot and reported by
  * lr_views_check (which synchronises).  Per-view arrays are HOST arrays of length n_views holding DEVICE
  * pointers (viewmatrices, projmatrices, cam_positions, dL_dpix [3,H,W], optional out_color [3,H,W] and
