@@ -538,6 +538,42 @@ def test_view_batch_equals_autograd_accumulation(hip_device):
         small.check()
 
 
+@pytest.mark.parametrize("n_views", [1, 2, 5, 7])
+def test_view_batch_same_bits_for_every_number_of_chains(hip_device, n_views):
+    """lr_views_accumulate spreads a step's views over 1..4 chains -- the chain of the LAST view on the caller's stream, the
+    others on streams of the library, the accumulating kernels chained in view order by device-only events, the interleaved
+    accumulator zeroed behind the fork, each slot's overflow word reset by its first forward (csrc/api.hip views_core).  With the
+    kernel shapes pinned (they follow the number of views in flight otherwise), the sums must not depend on the number of chains
+    by a single bit -- twice per batch (streams, events and workspace re-used), from accumulators that start as they are left
+    -- and the step must be complete on the caller's stream when the call returns to it (the comparison reads on that stream)."""
+    from luciddreamer_amd import _lib, parallel
+    P, W, H = 25_000, 256, 160
+    cloud = {k: v.to(hip_device) for k, v in synthetic.make_cloud(P, "band", 6).items()}
+    cams = [c.to(hip_device) for c in cameras.rotate360_path(W, H, n_views=7)][:n_views]
+    g = synthetic.upstream_grad(H, W).to(hip_device)
+    bg = torch.tensor([0.1, 0.0, 0.2], device=hip_device)
+    shapes = {"means3D": (P, 3), "means2D": (P, 3), "opacity": (P, 1), "sh": (P, 16, 3), "scales": (P, 3), "rotations": (P, 4)}
+    _lib.tune_set("blend_quad", 2)
+    _lib.tune_set("fwd_pair", 2)
+    try:
+        want = None
+        for n_streams in (1, 2, 3, 4):
+            batch = parallel.ViewBatch(cams, [g] * n_views, 3, bg, binning_capacity=400_000, n_streams=n_streams)
+            for _ in range(2):
+                acc = {k: torch.zeros(s, device=hip_device) for k, s in shapes.items()}
+                batch.run(cloud["means3D"], cloud["opacities"], cloud["scales"], cloud["rotations"], cloud["shs"], acc)
+                got = {k: v.clone() for k, v in acc.items()}          # on the caller's stream, right behind the call
+                batch.check()
+                if want is None:
+                    want = got
+                    assert all(float(v.abs().sum()) > 0 for v in want.values())
+                for k in shapes:
+                    assert torch.equal(got[k], want[k]), (n_streams, k)
+    finally:
+        _lib.tune_set("blend_quad", -1)
+        _lib.tune_set("fwd_pair", -1)
+
+
 def test_view_batch_with_fewer_views_than_streams(hip_device):
     """One view on a 3-stream ViewBatch (8 views over 8 GPUs leave 1 view per rank): the overflow words of the unused
     slots of a torch.empty workspace must not be read as garbage by check()."""
