@@ -880,6 +880,9 @@ def main():
                     "exchange_detail": exchange_detail if exchange_detail is not None else exchange_phases,
                     "dist_backend": backend, "dist_world_size": backend_world, "collective_check": collective_check,
                     "streams_per_rank": args.streams,
+                    "view_chains": (f"{args.streams} chains of views in flight: the last view's chain on the caller's stream, "
+                                    f"{max(0, args.streams - 1)} on streams of the library (csrc/api.hip views_core)"
+                                    if args.api in ("views", "views-loss") else f"parallel.ViewStreams({args.streams})"),
                     "api": args.api, "exchange": args.exchange, "host_issue_ms_per_step": round(host_issue_ms, 3),
                     "lr_version": _lib.lib().lr_version().decode()})
         if os.environ.get("LR_TUNE"):
