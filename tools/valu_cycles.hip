@@ -27,6 +27,12 @@ constexpr int ITER = 32768;      // ~0.6 ms per wave: every workgroup of a launc
 #define S_CMPS(i)  "v_cmp_lt_f32 s[20:21], %" #i ", %8\n\t"
 #define S_CMPV(i)  "v_cmp_lt_f32 vcc, %" #i ", %8\n\t"
 #define S_CND(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
+#define S_CND64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[20:21]\n\t"
+#define S_CND0(i)  "v_cndmask_b32_e64 %" #i ", 0, %" #i ", s[20:21]\n\t"
+#define S_CMPCND(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n\tv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n\t"
+#define S_CNDE64V(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, vcc\n\t"
+#define S_CMP_MOV_CND(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n\tv_mov_b32 %" #i ", %" #i "\n\tv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n\t"
+#define S_CMP_CND_CND(i) "v_cmp_lt_f32 vcc, %" #i ", %8\n\tv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n\tv_cndmask_b32 %" #i ", %" #i ", %8, vcc\n\t"
 #define S_DPPQ(i)  "v_add_f32_dpp %" #i ", %" #i ", %" #i " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
 #define S_DPPR(i)  "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
 #define S_DPPB(i)  "v_add_f32_dpp %" #i ", %" #i ", %" #i " row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
@@ -40,6 +46,8 @@ __global__ void __launch_bounds__(256) k(unsigned long long* ticks, float* sink,
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = seed + i + threadIdx.x;
     const float m = 1.0000001f, c = 1e-9f;
+    // a lane mask for the selects that read an SGPR pair: every other lane
+    asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555\n\ts_mov_b64 vcc, s[20:21]" ::: "s20", "s21", "vcc");
     __syncthreads();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < ITER; it++) {
@@ -58,6 +66,13 @@ __global__ void __launch_bounds__(256) k(unsigned long long* ticks, float* sink,
         if (MODE == 12) OP8(S_DPPB);
         if (MODE == 13) OP8(S_MOV);
         if (MODE == 14) OP8(S_SUB);
+        if (MODE == 17) OP8(S_CND64);
+        if (MODE == 18) OP8(S_CND0);
+        if (MODE == 19) OP8(S_CMPCND);
+        if (MODE == 20) { asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(a[0]), "v"(m) : "vcc"); OP8(S_CND); }       // vcc from ONE VALU compare
+        if (MODE == 21) OP8(S_CNDE64V);        // the same select in the VOP3 encoding, vcc named explicitly
+        if (MODE == 22) OP8(S_CMP_MOV_CND);    // compare -> unrelated VALU instruction -> select
+        if (MODE == 23) OP8(S_CMP_CND_CND);    // compare -> two selects on the same vcc
         if (MODE == 15) {      // lane swaps: four independent pairs
             asm volatile("v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
                          "v_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\t"
@@ -124,6 +139,13 @@ int main()
     run<7>("v_cmp_lt_f32 -> sgpr pair", dticks, dsink);
     run<8>("v_cmp_lt_f32 -> vcc", dticks, dsink);
     run<9>("v_cndmask_b32 (vcc)", dticks, dsink);
+    run<17>("v_cndmask_b32_e64 (sgpr pair)", dticks, dsink);
+    run<18>("v_cndmask_b32_e64 0, x (sgpr pair)", dticks, dsink);
+    run<19>("v_cmp_lt_f32 vcc + v_cndmask (2 instr)", dticks, dsink);
+    run<20>("1 v_cmp -> vcc, then 8 v_cndmask (vcc)", dticks, dsink);
+    run<21>("v_cndmask_b32_e64 ..., vcc (VOP3)", dticks, dsink);
+    run<22>("v_cmp, v_mov, v_cndmask (3 instr)", dticks, dsink);
+    run<23>("v_cmp, v_cndmask, v_cndmask (3 instr)", dticks, dsink);
     run<5>("v_exp_f32", dticks, dsink);
     run<6>("v_rcp_f32", dticks, dsink);
     run<10>("v_add_f32_dpp quad_perm", dticks, dsink);
