@@ -21,6 +21,9 @@ except ImportError as e:                                        # pragma: no cov
         f"({e}); build it with `python -m luciddreamer_amd.build` (needs lib/liblucid_raster.so). "
         "There is no CPU / pure-Python fallback.") from e
 
+from . import _lib as _lib_check
+_lib_check.assert_single_copy()                                 # the binding and ctypes must be on ONE build of the library
+
 NUM_CHANNELS = 3
 # order of rasterize_gaussians_backward's result tuple (RAST/rasterize_points.cu:199) = order of `accumulate`
 GRAD_ORDER = ("means2D", "colors", "opacity", "means3D", "cov3D", "sh", "scales", "rotations")

@@ -36,6 +36,22 @@ EXPORTS = ("lr_last_error", "lr_version", "lr_geom_bytes", "lr_img_bytes", "lr_b
            "lr_views_train_workspace_bytes", "lr_views_train_accumulate", "lr_views_train_check")
 
 
+def assert_single_copy():
+    """One library instance per process: raises if two DIFFERENT liblucid_raster.so files are mapped -- LR_LIB_DIR set without the
+    same directory on LD_LIBRARY_PATH leaves the compiled binding on the default build while ctypes loads the other one: two sets of
+    per-stream scratch, forward logs and tuning state, wrong answers from every query that crosses them, and (measured, round 6)
+    a C3 step 1.5 % slower.  Called behind both loads (here and in _C.py); whichever comes second sees both."""
+    try:
+        with open("/proc/self/maps") as f:
+            paths = {ln.split()[-1] for ln in f if ln.rstrip().endswith("liblucid_raster.so")}
+    except OSError:                                                          # no procfs: nothing to check with
+        return
+    real = {os.path.realpath(p) for p in paths}
+    if len(real) > 1:
+        raise RuntimeError("luciddreamer_amd: two copies of liblucid_raster.so in this process (" + ", ".join(sorted(real)) +
+                           "): LR_LIB_DIR needs the same directory on LD_LIBRARY_PATH (tools/diag_env.sh sets both)")
+
+
 def lib():
     """Load the library (built by `python -m luciddreamer_amd.build` / __graft_entry__.build())."""
     global _lib
@@ -49,6 +65,7 @@ def lib():
                 f"luciddreamer_amd: HIP library {LIB_PATH} is missing -- build it with "
                 "`python -m luciddreamer_amd.build` (hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
         L = ctypes.CDLL(LIB_PATH)
+        assert_single_copy()
         vp, ci, cf, ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
         L.lr_last_error.restype = ctypes.c_char_p
         L.lr_last_error.argtypes = []

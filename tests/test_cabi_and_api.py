@@ -126,6 +126,28 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.lib()
 
 
+def test_two_builds_of_the_library_in_one_process_are_refused(tmp_path):
+    """LR_LIB_DIR without the same directory on LD_LIBRARY_PATH: ctypes loads the named build, the compiled binding the default
+    one -- two sets of library state in one process (and, measured, a slower step).  Refused at the second load, whichever it
+    is; with both variables set (tools/diag_env.sh) the process is on one build."""
+    import shutil
+    import subprocess
+    import sys
+    other = tmp_path / "lib_other"
+    other.mkdir()
+    shutil.copy(os.path.join(ROOT, "luciddreamer_amd", "lib", "liblucid_raster.so"), other / "liblucid_raster.so")
+    code = "from luciddreamer_amd import _lib; _lib.lib(); from luciddreamer_amd import _C; print('LOADED', _lib.LIB_PATH)"
+    env = dict(os.environ, LR_LIB_DIR=str(other), PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "two copies of liblucid_raster.so" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
+    code2 = "from luciddreamer_amd import _C, _lib; _lib.lib(); print('LOADED', _lib.LIB_PATH)"      # the other order of the loads
+    r = subprocess.run([sys.executable, "-c", code2], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "two copies of liblucid_raster.so" in r.stderr, r.stdout[-500:] + r.stderr[-1500:]
+    env["LD_LIBRARY_PATH"] = str(other) + os.pathsep + os.environ.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and f"LOADED {other}" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
 def test_product_code_never_imports_the_oracle():
     """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
     may import it."""
